@@ -1,0 +1,193 @@
+/*
+ * unet_hip.h -- C ABI of libunet_hip.so: the MI355X (gfx950) kernels behind the UNet
+ * segmentation train-step path.
+ *
+ * The reference (Florescence/UNet-Medical-Image-Contour-Segmentation) has no FFI of its own:
+ * its hot path is the torch.nn surface of unet/unet_parts.py, utils/dice_score.py,
+ * utils/boundary_loss.py and train.py:113-159.  Each entry point below
+ * names the reference statement(s) it replaces.  Conventions for every function:
+ *
+ *   - plain pointers and sizes only; device pointers unless a parameter says "host";
+ *   - activations are NHWC ("channels_last", train.py:113,262): element (b,h,w,c) of a tensor
+ *     with pixel stride `ld` (elements) lives at ((b*H + h)*W + w)*ld + c.  `ld` >= C lets a
+ *     tensor be a channel slice of a wider buffer (zero-copy torch.cat of unet_parts.py:95);
+ *   - `dt` is the activation dtype: UH_F32 or UH_BF16; statistics, reductions, weights' master
+ *     copies and all gradients of parameters are fp32;
+ *   - no allocation, no host sync, no global mutable state inside: workspaces are caller owned,
+ *     kernels are enqueued on `stream` (a hipStream_t) and the call returns immediately;
+ *   - returns 0 on success, a negative UH_E* code otherwise; uh_last_error() gives the text
+ *     (thread-local).  The Python shim raises RuntimeError from it.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uh_stream;            /* hipStream_t */
+
+enum { UH_F32 = 0, UH_BF16 = 1 };
+enum { UH_OK = 0, UH_EINVAL = -1, UH_ELAUNCH = -2, UH_EWORKSPACE = -3 };
+
+const char* uh_last_error(void);
+int uh_version(void);
+
+/* ---- parameter layout --------------------------------------------------------------------
+ * nn.Conv2d weight [O,I,3,3] fp32 with arbitrary strides (contiguous or channels_last,
+ * train.py:262) -> KRSC [O][3][3][I] in `dt` (w_fwd) and the flipped/transposed copy
+ * [I][3][3][O] (w_dgrad, may be NULL) that turns conv3x3_fwd into the data-gradient conv. */
+int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
+                 void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
+/* KRSC fp32 weight gradient -> gradient tensor with the parameter's own strides. */
+int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int64_t sH, int64_t sW,
+                    int Cout, int Cin, uh_stream stream);
+
+/* ---- nn.Conv2d(k=3, padding=1, bias=False)  (unet_parts.py:15,18) --------------------------
+ * y[b,h,w,o] = sum_{r,s,i} x[b,h+r-1,w+s-1,i] * w[o][r][s][i]; the input is the virtual channel
+ * concat of (x0:C0) and (x1:C1) (x1 may be NULL with C1 = 0).
+ * stat_partials (may be NULL): [uh_conv3x3_stat_slabs()][2][Cout] fp32, per-slab sum and sum of
+ * squares of the stored y over the slab's pixels -- BatchNorm2d batch statistics
+ * (unet_parts.py:16,19) without a second pass.  With w = w_dgrad this is conv backward-data. */
+int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int dt);
+int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
+                   const void* w, void* y, int ldy, int Cout, float* stat_partials,
+                   int B, int H, int W, int dt, uh_stream stream);
+/* conv backward-weights: dw[o][r][s][i] = sum_{b,h,w} dy[b,h,w,o] * x[b,h+r-1,w+s-1,i] (fp32 KRSC). */
+size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
+int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
+                     const void* x1, int C1, int ld1, float* dw_krsc, int Cout,
+                     void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
+
+/* ---- nn.BatchNorm2d + nn.ReLU(inplace)  (unet_parts.py:16-17,19-20) ------------------------
+ * finalize: reduce the conv's stat slabs -> mean, rstd = 1/sqrt(var_biased + eps),
+ * scale = gamma*rstd, shift = beta - mean*scale; running stats (may be NULL) updated in place with
+ * `momentum` and the UNBIASED variance (n = pixels per channel). */
+int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,
+                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                   uh_stream stream);
+/* eval mode: scale/shift from the running statistics. */
+int uh_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, float* scale, float* shift,
+                      uh_stream stream);
+/* z = max(y*scale + shift, 0) */
+int uh_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift,
+                     void* z, int ldz, int64_t npix, int C, int dt, uh_stream stream);
+/* backward, pass 1: per-channel sums of dz*[z>0] and dz*[z>0]*xhat -> partials [nblk][2][C];
+ * returns the number of partial rows it will write through uh_bn_bwd_nblk(). */
+int uh_bn_bwd_nblk(int64_t npix, int C);
+int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, int ldy,
+                          const float* scale, const float* shift, const float* mean, const float* rstd,
+                          float* partials, int64_t npix, int C, int dt, uh_stream stream);
+/* backward, pass 2: dgamma = sum2, dbeta = sum1 (written fp32), and
+ * dy = scale*(dz*[z>0] - sum1/n - xhat*sum2/n). */
+int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int ldy,
+                         const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* partials, int nblk, float* dgamma, float* dbeta,
+                         void* dy, int lddy, int64_t npix, int C, int dt, uh_stream stream);
+
+/* ---- nn.MaxPool2d(2)  (unet_parts.py:32) -------------------------------------------------- */
+int uh_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int dt,
+                    uh_stream stream);
+/* dx = (dskip ? dskip : 0) + route(dy) to the FIRST maximum of each 2x2 window in row-major
+ * order; rows/cols beyond 2*floor(H/2) get only dskip. */
+int uh_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int ldskip,
+                    void* dx, int lddx, int B, int H, int W, int C, int dt, uh_stream stream);
+
+/* ---- nn.Upsample(2, 'bilinear', align_corners=True) + F.pad  (unet_parts.py:70,85-88) ------
+ * x [B,h,w,C] -> y [B,Ho,Wo,C]: the 2h x 2w upsampled image sits at (pad_top, pad_left), the rest
+ * of y is zero filled. */
+int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B, int h, int w, int C,
+                      int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
+int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int B, int h, int w, int C,
+                      int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
+
+/* ---- nn.ConvTranspose2d(Cin, Cout, 2, 2) + F.pad  (unet_parts.py:73,85-88) -----------------
+ * w is the parameter itself: [Cin][Cout][2][2] fp32 contiguous; bias [Cout] fp32. */
+int uh_convt2x2_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy,
+                    int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int pad_top, int pad_left,
+                    int dt, uh_stream stream);
+int uh_convt2x2_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx,
+                      int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int pad_top, int pad_left,
+                      int dt, uh_stream stream);
+size_t uh_convt2x2_wgrad_ws_bytes(int B, int h, int w_, int Cin, int Cout);
+int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, float* dbias,
+                      void* ws, size_t ws_bytes, int B, int h, int w_, int Cin, int Cout,
+                      int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
+
+/* ---- OutConv: nn.Conv2d(Cin, ncls, 1) with bias  (unet_parts.py:103) -----------------------
+ * w [ncls][Cin] fp32, bias [ncls] fp32; logits are fp32 [npix][ncls]. */
+int uh_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias, float* logits,
+                   int64_t npix, int Cin, int ncls, int dt, uh_stream stream);
+int uh_conv1x1_dgrad(const float* dlogits, const float* w, void* dx, int lddx,
+                     int64_t npix, int Cin, int ncls, int dt, uh_stream stream);
+size_t uh_conv1x1_wgrad_ws_bytes(int64_t npix, int Cin, int ncls);
+int uh_conv1x1_wgrad(const float* dlogits, const void* x, int ldx, float* dw, float* dbias,
+                     void* ws, size_t ws_bytes, int64_t npix, int Cin, int ncls, int dt, uh_stream stream);
+
+/* ---- losses ------------------------------------------------------------------------------
+ * Binary path (train.py:118-134): t = (mask / mask_div) as float (train.py:119 uses // 2), or t
+ * taken from `target_f` when mask is NULL.  sums[0..3] = { sum softplus-BCE, sum sigmoid*t,
+ * sum sigmoid, sum t } (fp32, caller zeroes nothing: the kernel overwrites). */
+size_t uh_loss_ws_bytes(int64_t n);
+int uh_bce_dice_sums(const float* logits, const int64_t* mask, int mask_div, const float* target_f,
+                     int64_t n, float* sums, void* ws, size_t ws_bytes, uh_stream stream);
+/* dlogits = gscale[0] * ( w_bce*(sigmoid - t)/n + w_dice * d(1 - dice)/dlogit ) with the Dice
+ * ratio formed from `sums` (global-batch sums; after a cross-rank all-reduce they give the
+ * single-process reference's gradient).  dice_score.py:14-18 including the sets_sum==0 branch.
+ * gscale is a device pointer (upstream gradient of the scalar loss); n_mean = element count of
+ * the BCE mean (the GLOBAL batch when sharded). */
+int uh_bce_dice_grad(const float* logits, const int64_t* mask, int mask_div, const float* target_f,
+                     int64_t n, const float* sums, double n_mean, float w_bce, float w_dice,
+                     const float* gscale, float* dlogits, uh_stream stream);
+/* Multi-class path (train.py:136-142): logits [npix][ncls] fp32, mask int64 class ids.
+ * sums = { sum CE, inter[c]..., psum[c]..., tsum[c]... } (1 + 3*ncls floats). */
+int uh_ce_dice_sums(const float* logits, const int64_t* mask, int64_t npix, int ncls, float* sums,
+                    void* ws, size_t ws_bytes, uh_stream stream);
+int uh_ce_dice_grad(const float* logits, const int64_t* mask, int64_t npix, int ncls,
+                    const float* sums, double n_mean, float w_ce, float w_dice, const float* gscale,
+                    float* dlogits, uh_stream stream);
+/* dice_coeff (dice_score.py:5-25) for arbitrary float inputs: per-group sums {sum x*t, sum x, sum t}
+ * over `ngroups` contiguous groups of `group_len` elements -> sums [ngroups][3]. */
+int uh_dice_sums(const float* x, const float* t, int64_t ngroups, int64_t group_len, float* sums,
+                 void* ws, size_t ws_bytes, uh_stream stream);
+/* boundary_loss (boundary_loss.py:5-118), value only.  pred [B][H][W] fp32 with element stride
+ * `pstride` (4-D [B,C,H,W]-logical channel select = base pointer + stride), target fp32 [B][H][W];
+ * out[0] = loss.  ws from uh_loss_ws_bytes(B*H*W). */
+int uh_boundary_loss(const float* pred, int64_t pstride, int64_t bstride, const float* target, int B, int H, int W,
+                     int edge_width, float edge_weight, float smooth, float* out,
+                     void* ws, size_t ws_bytes, uh_stream stream);
+
+/* ---- clip_grad_norm_ + RMSprop  (train.py:80-81,157-158) -----------------------------------
+ * Flat-buffer form: all parameters / gradients / optimizer states live in four equally laid out
+ * fp32 buffers of n elements (the Python shim points every nn.Parameter at a view of them).
+ * uh_grad_sumsq: norm_out[0] = sqrt(sum g^2)  (clip_grad_norm_'s total_norm).
+ * uh_rmsprop_step: coef = min(1, max_norm/(norm+1e-6)); g *= coef (written back, as
+ * clip_grad_norm_ does); g += wd*p; v = alpha*v + (1-alpha)*g^2; buf = mu*buf + g/(sqrt(v)+eps);
+ * p -= lr*buf.  total_norm is a device pointer (no host sync); max_norm <= 0 disables clipping. */
+size_t uh_optim_ws_bytes(int64_t n);
+int uh_grad_sumsq(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, uh_stream stream);
+int uh_rmsprop_step(float* p, float* g, float* square_avg, float* momentum_buf, int64_t n,
+                    const float* total_norm, float max_norm, float lr, float alpha, float eps,
+                    float weight_decay, float momentum, uh_stream stream);
+
+/* ---- scalar assembly ------------------------------------------------------------------------
+ * dice_coeff from per-group sums {sum x*t, sum x, sum t} (dice_score.py:14-25): out[0] = mean over
+ * groups of (2I+eps)/(S+eps) with S := 2I where S == 0. */
+int uh_dice_from_sums(const float* sums, int64_t ngroups, float eps, float* out, uh_stream stream);
+/* train.py:121-134: out = { total, bce_mean, dice_loss, boundary } with
+ * total = bce_mean + dice_loss + w_boundary*boundary[0]; sums from uh_bce_dice_sums. */
+int uh_seg_loss_binary_finish(const float* sums, double n_mean, const float* boundary, float w_boundary,
+                              float* out, uh_stream stream);
+/* train.py:137-142: out = { total, ce_mean, dice_loss, boundary }, sums from uh_ce_dice_sums. */
+int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double n_mean, const float* boundary,
+                                  float w_boundary, float* out, uh_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,322 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI via the
+drop-in modules, against (a) the golden fixtures produced by the reference's own modules and (b) the
+CPU oracle (oracle/) on seeded inputs.  Tolerances: fp32 path 1e-3 relative to the tensor's max
+(BASELINE.json north_star), bf16 path 3e-2 (documented: bf16 activations, fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; the product path has no CPU fallback")
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def check(a, b, tol, what=""):
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: max-rel error {e:.3e} > {tol:.1e}"
+
+
+def load_sd(mod, rec, prefix):
+    sd = {k[len(prefix):]: T(v) for k, v in rec.items() if k.startswith(prefix)}
+    mod.load_state_dict(sd)
+
+
+def run_block(mod, rec, dev, n_in, tol=1e-3):
+    import unet_amd  # noqa: F401
+    mod = mod.to(dev)
+    load_sd(mod, rec, "sd0.")
+    mod.train()
+    xs = [T(rec[f"x{i}"], dev).requires_grad_(True) for i in range(n_in)]
+    y = mod(*xs)
+    check(y, rec["y"], tol, "fwd")
+    y.backward(T(rec["cot"], dev))
+    for i in range(n_in):
+        check(xs[i].grad, rec[f"dx{i}"], tol, f"dx{i}")
+    for k, p in mod.named_parameters():
+        check(p.grad, rec["grad." + k], 2e-3, "grad " + k)
+    sd1 = {k[4:]: v for k, v in rec.items() if k.startswith("sd1.")}
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            check(v, sd1[k], 1e-4, k)
+        if "num_batches" in k:
+            assert int(v) == int(sd1[k])
+    mod.eval()
+    with torch.no_grad():
+        check(mod(*[x.detach() for x in xs]), rec["y_eval"], tol, "eval fwd")
+
+
+@pytest.mark.parametrize("name,args", [("g1_doubleconv_3_8", (3, 8)), ("g1_doubleconv_4_8_mid6", (4, 8, 6)),
+                                       ("g1_doubleconv_32_64", (32, 64))])
+def test_double_conv_golden(name, args):
+    import unet_amd
+    run_block(unet_amd.DoubleConv(*args), load_golden(name), _dev(), 1)
+
+
+@pytest.mark.parametrize("name", ["g2_down_8_16", "g2_down_8_16_odd"])
+def test_down_golden(name):
+    import unet_amd
+    run_block(unet_amd.Down(8, 16), load_golden(name), _dev(), 1)
+
+
+@pytest.mark.parametrize("name,bilinear", [("g3_up_bilinear_16_8", True), ("g3_up_bilinear_16_8_oddpad", True),
+                                           ("g4_up_convt_16_8", False), ("g4_up_convt_16_8_oddpad", False)])
+def test_up_golden(name, bilinear):
+    import unet_amd
+    run_block(unet_amd.Up(16, 8, bilinear), load_golden(name), _dev(), 2)
+
+
+@pytest.mark.parametrize("ncls", [1, 4])
+def test_outconv_golden(ncls):
+    import unet_amd
+    run_block(unet_amd.OutConv(8, ncls), load_golden(f"g5_outconv_8_{ncls}"), _dev(), 1)
+
+
+def test_dice_golden():
+    import unet_amd
+    dev = _dev()
+    r = load_golden("g6_dice")
+    p3, t3 = T(r["p3"], dev), T(r["t3"], dev)
+    check(unet_amd.dice_coeff(p3, t3, True), r["dice3_rbf_true"], 1e-5)
+    check(unet_amd.dice_coeff(p3, t3, False), r["dice3_rbf_false"], 1e-5)
+    check(unet_amd.dice_coeff(p3[0], t3[0]), r["dice2"], 1e-5)
+    pr = p3.clone().requires_grad_(True)
+    loss = unet_amd.dice_loss(pr, t3)
+    check(loss, r["loss3"], 1e-5)
+    loss.backward()
+    check(pr.grad, r["loss3_grad"], 1e-4)
+    p4, t4 = T(r["p4"], dev), T(r["t4"], dev)
+    check(unet_amd.multiclass_dice_coeff(p4, t4, True), r["mdice_rbf_true"], 1e-5)
+    check(unet_amd.multiclass_dice_coeff(p4, t4, False), r["mdice_rbf_false"], 1e-5)
+    pr = p4.clone().requires_grad_(True)
+    unet_amd.dice_loss(pr, t4, multiclass=True).backward()
+    check(pr.grad, r["mloss_grad"], 1e-4)
+    z = torch.zeros(2, 6, 6, device=dev)
+    check(unet_amd.dice_coeff(z, z, True), r["dice_zero_rbf_true"], 1e-6)
+    check(unet_amd.dice_coeff(z, z, False), r["dice_zero_rbf_false"], 1e-6)
+    check(unet_amd.dice_coeff(T(r["pz"], dev), T(r["tz"], dev), False), r["dice_halfzero_rbf_false"], 1e-5)
+    with pytest.raises(AssertionError):
+        unet_amd.dice_coeff(p3[0], t3[0], reduce_batch_first=True)
+    with pytest.raises(AssertionError):
+        unet_amd.dice_coeff(p3, t3[:, :5])
+
+
+@pytest.mark.parametrize("case", ["train_style", "coded255", "sigmoid_branch", "interior_empty", "edge_zero",
+                                  "fourd_c4", "fourd_c1_prob", "odd_b3"])
+def test_boundary_golden(case):
+    import unet_amd
+    dev = _dev()
+    r = load_golden("g7_boundary")
+    ew, wt = r[case + ".kw"]
+    got = unet_amd.boundary_loss(T(r[case + ".pred"], dev), T(r[case + ".target"], dev), edge_width=int(ew),
+                                 edge_weight=float(wt))
+    assert not got.requires_grad
+    check(got, r[case + ".loss"], 2e-5, case)
+
+
+def _run_traj(name, cls, args, n_classes, lr=1e-5, bmc=None, widths=None):
+    import unet_amd
+    dev = _dev()
+    r = load_golden(name)
+    model = (unet_amd.UNetDepth(*args, widths=widths) if widths else cls(*args)).to(dev)
+    load_sd(model, r, "sd0.")
+    stepper = unet_amd.TrainStepper(model, lr=lr, amp=False)
+    nsteps = sum(1 for k in r if k.endswith(".images"))
+    for s in range(nsteps):
+        im, mk = T(r[f"s{s}.images"], dev), T(r[f"s{s}.masks"], dev)
+        model.train()
+        terms = unet_amd.train_step(model, stepper.optimizer, im, mk, amp=False, boundary_weight=bmc)
+        tl = 1e-3 if s == 0 else 5e-3
+        check(terms["logits"], r[f"s{s}.logits"], tl, f"logits s{s}")
+        check(terms["loss"], r[f"s{s}.loss"], 1e-4 if s == 0 else 3e-3, f"loss s{s}")
+        check(terms["dice"], r[f"s{s}.dice"], 1e-4 if s == 0 else 3e-3, f"dice s{s}")
+        if "bce" in terms:
+            check(terms["bce"], r[f"s{s}.bce"], 1e-4 if s == 0 else 3e-3, f"bce s{s}")
+        if "ce" in terms:
+            check(terms["ce"], r[f"s{s}.ce"], 1e-4 if s == 0 else 3e-3, f"ce s{s}")
+        check(terms["boundary"], r[f"s{s}.boundary"], 1e-4 if s == 0 else 2e-2, f"boundary s{s}")
+        check(terms["grad_norm"], r[f"s{s}.grad_norm"], 1e-3 if s == 0 else 3e-2, f"grad_norm s{s}")
+        if s == 0:
+            named = dict(model.named_parameters())
+            for k, p in named.items():
+                g = stepper.optimizer.grad_of(p)       # clipped gradient, as the fixture stores it
+                check(g, r[f"s0.grad.{k}"], 5e-3, "grad " + k)
+    final = {k[len(f"sd{nsteps}."):]: v for k, v in r.items() if k.startswith(f"sd{nsteps}.")}
+    for k, v in model.state_dict().items():
+        if "num_batches" in k:
+            assert int(v) == int(final[k])
+        else:
+            check(v, final[k], 5e-3, "final " + k)
+
+
+def test_unet_t_bilinear_trajectory():
+    import unet_amd
+    _run_traj("g8_unet_t_bilinear", unet_amd.UNet_T, (1, 1, True), 1)
+
+
+def test_unet_t_convt_trajectory():
+    import unet_amd
+    _run_traj("g8_unet_t_convt", unet_amd.UNet_T, (1, 1, False), 1)
+
+
+def test_unet_t_multiclass_trajectory():
+    import unet_amd
+    _run_traj("g8_unet_t_multiclass", unet_amd.UNet_T, (3, 4, True), 4)
+
+
+def test_depth5_multiclass_trajectory():
+    import unet_amd
+    _run_traj("g11_depth5_multiclass", None, (3, 4, True), 4, bmc=0.2, widths=(4, 8, 16, 32, 64, 128))
+
+
+@pytest.mark.parametrize("name,bilinear", [("g10_eval_unet_t_bilinear", True), ("g10_eval_unet_t_convt", False)])
+def test_eval_masks_bit_exact(name, bilinear):
+    import unet_amd
+    dev = _dev()
+    r = load_golden(name)
+    model = unet_amd.UNet_T(1, 1, bilinear).to(dev)
+    load_sd(model, r, "sd.")
+    model.eval()
+    with torch.no_grad():
+        logits = model(T(r["images"], dev))
+    check(logits, r["logits"], 1e-3, "eval logits")
+    pred = (logits.squeeze(1) > 0).cpu().numpy()
+    margin = np.abs(r["logits"]).squeeze(1)
+    safe = margin > 1e-3 * np.abs(r["logits"]).max()
+    assert (pred == r["mask_pred"])[safe].all(), "argmax mask differs where |logit| margin is safe"
+    assert (pred != r["mask_pred"]).mean() < 1e-3
+    batches = [{"image": T(r["images"]), "mask": T(r["masks"])}]
+    dice, _, _ = unet_amd.evaluate(model, batches, dev, amp=False)
+    check(dice, r["dice"], 2e-3, "dice")
+
+
+# ------------------------------------------------------------------ MFMA kernels vs the CPU oracle
+def _oracle_block(kind, st, xs, cot, bilinear=True, dtype=torch.float64):
+    from oracle import unet_ref as U
+    st = {("x." + k): (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
+    keys = U.param_keys(st)
+    work = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in st.items()}
+    xs = [x.to(dtype).requires_grad_(True) for x in xs]
+    if kind == "double_conv":
+        y = U.double_conv(xs[0], work, "x", True, {})
+    elif kind == "up":
+        y = U.up(xs[0], xs[1], work, "x", bilinear, True, {})
+    else:
+        y = U.down(xs[0], work, "x", True, {})
+    grads = torch.autograd.grad(y, xs + [work[k] for k in keys], cot.to(dtype))
+    return y.detach(), grads[:len(xs)], {k[2:]: g for k, g in zip(keys, grads[len(xs):])}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 40, 56), (128, 64, 33, 17), (32, 256, 16, 16)])
+def test_double_conv_mfma_vs_oracle(dtype, tol, cin, cout, h, w):
+    import unet_amd
+    dev = _dev()
+    torch.manual_seed(cin + cout)
+    mod = unet_amd.DoubleConv(cin, cout)
+    if dtype == torch.float32:
+        mod = mod.to(memory_format=torch.channels_last)
+    x = torch.randn(2, cin, h, w)
+    cot = torch.randn(2, cout, h, w)
+    st = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    yo, dxo, go = _oracle_block("double_conv", st, [x], cot)
+    mod = mod.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+        y = mod(xg)
+    y.float().backward(cot.to(dev))
+    check(y.float(), yo, tol, "y")
+    check(xg.grad, dxo[0], tol * 2, "dx")
+    for k, p in mod.named_parameters():
+        check(p.grad, go[k], tol * 3, "grad " + k)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("bilinear", [True, False])
+def test_up_mfma_two_sources_vs_oracle(dtype, tol, bilinear):
+    import unet_amd
+    dev = _dev()
+    torch.manual_seed(5)
+    mod = unet_amd.Up(128, 64, bilinear)
+    cx1 = 64 if bilinear else 128
+    x1 = torch.randn(2, cx1, 12, 19)
+    x2 = torch.randn(2, 64, 25, 39)          # odd sizes: pad rule + partial tiles
+    cot = torch.randn(2, 64, 25, 39)
+    st = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    yo, dxo, go = _oracle_block("up", st, [x1, x2], cot, bilinear)
+    mod = mod.to(dev).train()
+    a, b = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+        y = mod(a, b)
+    y.float().backward(cot.to(dev))
+    check(y.float(), yo, tol, "y")
+    check(a.grad, dxo[0], tol * 2, "dx1")
+    check(b.grad, dxo[1], tol * 2, "dx2")
+    for k, p in mod.named_parameters():
+        check(p.grad, go[k], tol * 3, "grad " + k)
+
+
+def test_full_unet_step_vs_oracle_fp32():
+    """UNet(1,1,bilinear=True) at 2x1x64x64: MFMA conv / wgrad / dgrad kernels on every layer."""
+    import unet_amd
+    from oracle import step_ref as S
+    dev = _dev()
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=True)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(2, 1, 64, 64, generator=g)
+    masks = torch.randint(0, 3, (2, 64, 64), generator=g)
+    st = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    st64 = {k: (v.double() if v.is_floating_point() else v) for k, v in st.items()}
+    _, _, info = S.train_step(st64, None, images.double(), masks, n_classes=1, bilinear=True)
+    model = model.to(dev)
+    stepper = unet_amd.TrainStepper(model, amp=False)
+    terms = stepper.step(images.to(dev), masks.to(dev))
+    check(terms["logits"], info["logits"], 1e-3, "logits")
+    check(terms["loss"], info["loss"], 1e-4, "loss")
+    check(terms["grad_norm"], info["grad_norm"], 2e-3, "grad_norm")
+    coef = float(S.clip_coef(info["grad_norm"], 1.0))
+    for k, p in model.named_parameters():
+        check(stepper.optimizer.grad_of(p), info["grads"][k] * coef, 5e-3, "grad " + k)
+
+
+def test_full_unet_step_bf16_close_to_oracle():
+    import unet_amd
+    from oracle import step_ref as S
+    dev = _dev()
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=True)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(2, 1, 96, 64, generator=g)
+    masks = torch.randint(0, 3, (2, 96, 64), generator=g)
+    st = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    _, _, info = S.train_step(st, None, images, masks, n_classes=1, bilinear=True)
+    model = model.to(dev)
+    stepper = unet_amd.TrainStepper(model, amp=True)
+    terms = stepper.step(images.to(dev), masks.to(dev))
+    check(terms["logits"], info["logits"], 6e-2, "logits bf16")
+    check(terms["loss"], info["loss"], 2e-2, "loss bf16")
+    check(terms["grad_norm"], info["grad_norm"], 1e-1, "grad_norm bf16")
+
+
+def test_missing_gpu_tensor_fails_loudly():
+    import unet_amd
+    m = unet_amd.DoubleConv(3, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 8, 8))

@@ -1,0 +1,309 @@
+// bn.hip -- nn.BatchNorm2d (+ fused nn.ReLU) of unet/unet_parts.py:16-17,19-20 for NHWC tensors.
+//
+// Forward statistics arrive as per-tile (sum, sum of squares) slabs written by the conv epilogue
+// (conv3x3.hip), so the forward needs no extra pass over y for the statistics:
+//   uh_bn_finalize     slabs -> mean / rstd / scale / shift (+ running stats, unbiased var, momentum)
+//   uh_bn_relu_apply   z = max(y*scale + shift, 0)                              (HBM-bound, 16 B/lane)
+// Backward (closed form):
+//   uh_bn_relu_bwd_reduce   per-block partial sums of dz*[z>0] and dz*[z>0]*xhat  (wave/LDS reductions)
+//   uh_bn_relu_bwd_apply    dgamma, dbeta, and dy = scale*(dzm - sum1/n - xhat*sum2/n)
+#include "uh_vec.h"
+
+// ------------------------------------------------------------------------------------ finalize
+// fold: slabs [nslab][2][C] -> in place, entry f*L holds the sum of slabs [f*L, min((f+1)*L, nslab))
+__global__ __launch_bounds__(256) void bn_stats_fold_kernel(float* __restrict__ stats, int nslab, int C, int L) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int f = blockIdx.y;
+    const int s0 = f * L, s1 = min(s0 + L, nslab);
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int s = s0 + sl; s < s1; s += 4) {
+            a += stats[((int64_t)s * 2 + 0) * C + c];
+            b += stats[((int64_t)s * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = a;
+    red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        stats[((int64_t)s0 * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        stats[((int64_t)s0 * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nfold, int L, int C, double n,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ rstd_o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int f = 0; f < nfold; ++f) {
+        s1 += (double)stats[((int64_t)f * L * 2 + 0) * C + c];
+        s2 += (double)stats[((int64_t)f * L * 2 + 1) * C + c];
+    }
+    double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma[c], bt = beta[c];
+    float sc = g * rstd;
+    scale[c] = sc;
+    shift[c] = bt - (float)mean * sc;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+        double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              float* scale, float* shift, float* mean, float* rstd, uh_stream stream) {
+    UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
+    UH_REQUIRE(nslab > 0 && C > 0 && n > 0, "uh_bn_finalize: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    int L = 1, nfold = nslab;
+    if (nslab > 64) {
+        L = (nslab + 63) / 64;
+        nfold = (nslab + L - 1) / L;
+        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + 63) / 64, nfold), dim3(256), 0, st, (float*)stat_partials,
+                           nslab, C, L);
+        UH_CHECK_LAUNCH("bn_stats_fold_kernel");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stat_partials, nfold, L, C, (double)n,
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    UH_CHECK_LAUNCH("bn_finalize_kernel");
+    return UH_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, int C,
+                                      float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = g[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = b[c] - rm[c] * sc;
+}
+
+extern "C" int uh_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift,
+                                 uh_stream stream) {
+    UH_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "uh_bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    UH_CHECK_LAUNCH("bn_eval_coeffs_kernel");
+    return UH_OK;
+}
+
+// ------------------------------------------------------------------------------------ apply
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ z, int ldz,
+                                                            int64_t npix, int C) {
+    const int G = C / V;
+    const int64_t total = npix * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = idx / G;
+        int c = (int)(idx - p * G) * V;
+        float v[V];
+        uh_load<T, V>(y + p * ldy + c, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = fmaxf(fmaf(v[i], scale[c + i], shift[c + i]), 0.f);
+        uh_store<T, V>(z + p * ldz + c, v);
+    }
+}
+
+static inline unsigned grid_for(int64_t total, int threads = 256, int cap = 256 * 16) {
+    int64_t g = (total + threads - 1) / threads;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* z, int ldz,
+                                int64_t npix, int C, int dt, uh_stream stream) {
+    UH_REQUIRE(y && z && scale && shift && npix > 0 && C > 0 && ldy >= C && ldz >= C, "uh_bn_relu_apply: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(z, ldz, C))
+            hipLaunchKernelGGL((bn_relu_apply_kernel<T, VEC>), dim3(grid_for(npix * (C / VEC))), dim3(256), 0, st,
+                               (const T*)y, ldy, scale, shift, (T*)z, ldz, npix, C);
+        else
+            hipLaunchKernelGGL((bn_relu_apply_kernel<T, 1>), dim3(grid_for(npix * C)), dim3(256), 0, st, (const T*)y, ldy,
+                               scale, shift, (T*)z, ldz, npix, C);
+    });
+    UH_CHECK_LAUNCH("bn_relu_apply_kernel");
+    return UH_OK;
+}
+
+// ------------------------------------------------------------------------------------ backward
+// Thread = (pixel lane, channel group of V).  Block covers a contiguous pixel range.
+extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
+    (void)C;
+    int64_t n = (npix + 511) / 512;
+    if (n > 2048) n = 2048;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
+                                                                 int ldy, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 float* __restrict__ partials, int64_t npix, int C) {
+    extern __shared__ float red[];   // [PL][2][GB*V]
+    const int G = C / V;                              // channel groups
+    const int GB = G < 256 ? G : 256;                 // groups handled per pass
+    const int PL = 256 / GB;                          // pixel lanes
+    const int g_in = threadIdx.x % GB, pl = threadIdx.x / GB;
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per;
+    const int64_t p1 = (p0 + per < npix) ? p0 + per : npix;
+    for (int gb = 0; gb < G; gb += GB) {
+        const int g = gb + g_in;
+        const bool act = (pl < PL) && (g < G);
+        const int c = g * V;
+        float s1[V], s2[V], sc[V], sh[V], mu[V], rs[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; }
+            for (int64_t p = p0 + pl; p < p1; p += PL) {
+                float d[V], yv[V];
+                uh_load<T, V>(dz + p * lddz + c, d);
+                uh_load<T, V>(y + p * ldy + c, yv);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float m = (fmaf(yv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
+                    s1[i] += m;
+                    s2[i] += m * (yv[i] - mu[i]) * rs[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                red[(pl * 2 + 0) * (GB * V) + g_in * V + i] = s1[i];
+                red[(pl * 2 + 1) * (GB * V) + g_in * V + i] = s2[i];
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2 * GB * V; k += 256) {
+            int which = k / (GB * V), cc = k - which * (GB * V);
+            if (gb * V + cc < C) {
+                float v = 0.f;
+                for (int q = 0; q < PL; ++q) v += red[(q * 2 + which) * (GB * V) + cc];
+                partials[((int64_t)blockIdx.x * 2 + which) * C + gb * V + cc] = v;
+            }
+        }
+    }
+}
+
+extern "C" int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, int ldy, const float* scale,
+                                     const float* shift, const float* mean, const float* rstd, float* partials,
+                                     int64_t npix, int C, int dt, uh_stream stream) {
+    UH_REQUIRE(dz && y && scale && shift && mean && rstd && partials, "uh_bn_relu_bwd_reduce: null pointer");
+    UH_REQUIRE(npix > 0 && C > 0 && lddz >= C && ldy >= C, "uh_bn_relu_bwd_reduce: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = uh_bn_bwd_nblk(npix, C);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C)) {
+            int G = C / VEC, GB = G < 256 ? G : 256, PL = 256 / GB;
+            size_t sm = (size_t)PL * 2 * GB * VEC * sizeof(float);
+            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, VEC>), dim3(nblk), dim3(256), sm, st, (const T*)dz, lddz,
+                               (const T*)y, ldy, scale, shift, mean, rstd, partials, npix, C);
+        } else {
+            int G = C, GB = G < 256 ? G : 256, PL = 256 / GB;
+            size_t sm = (size_t)PL * 2 * GB * sizeof(float);
+            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, 1>), dim3(nblk), dim3(256), sm, st, (const T*)dz, lddz,
+                               (const T*)y, ldy, scale, shift, mean, rstd, partials, npix, C);
+        }
+    });
+    UH_CHECK_LAUNCH("bn_relu_bwd_reduce_kernel");
+    return UH_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][4][64];   // double: sum(dz) cancels heavily behind a BatchNorm
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int s = sl; s < nblk; s += 4) {
+            a += (double)partials[((int64_t)s * 2 + 0) * C + c];
+            b += (double)partials[((int64_t)s * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = a;
+    red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        dbeta[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        dgamma[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
+                                                                int ldy, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, T* __restrict__ dy,
+                                                                int lddy, int64_t npix, int C, float inv_n) {
+    const int G = C / V;
+    const int64_t total = npix * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = idx / G;
+        int c = (int)(idx - p * G) * V;
+        float d[V], yv[V], o[V];
+        uh_load<T, V>(dz + p * lddz + c, d);
+        uh_load<T, V>(y + p * ldy + c, yv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float sc = scale[c + i];
+            float m = (fmaf(yv[i], sc, shift[c + i]) > 0.f) ? d[i] : 0.f;
+            float xh = (yv[i] - mean[c + i]) * rstd[c + i];
+            o[i] = sc * (m - dbeta[c + i] * inv_n - xh * dgamma[c + i] * inv_n);
+        }
+        uh_store<T, V>(dy + p * lddy + c, o);
+    }
+}
+
+extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int ldy, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, const float* partials,
+                                    int nblk, float* dgamma, float* dbeta, void* dy, int lddy, int64_t npix, int C,
+                                    int dt, uh_stream stream) {
+    UH_REQUIRE(dz && y && scale && shift && mean && rstd && partials && dgamma && dbeta && dy,
+               "uh_bn_relu_bwd_apply: null pointer");
+    UH_REQUIRE(npix > 0 && C > 0 && nblk > 0 && lddz >= C && ldy >= C && lddy >= C, "uh_bn_relu_bwd_apply: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partials, nblk, C, dgamma, dbeta);
+    UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    float inv_n = (float)(1.0 / (double)npix);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(dy, lddy, C))
+            hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, VEC>), dim3(grid_for(npix * (C / VEC))), dim3(256), 0, st,
+                               (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma,
+                               (const float*)dbeta, (T*)dy, lddy, npix, C, inv_n);
+        else
+            hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, 1>), dim3(grid_for(npix * C)), dim3(256), 0, st, (const T*)dz,
+                               lddz, (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma,
+                               (const float*)dbeta, (T*)dy, lddy, npix, C, inv_n);
+    });
+    UH_CHECK_LAUNCH("bn_relu_bwd_apply_kernel");
+    return UH_OK;
+}

@@ -1,0 +1,262 @@
+// pool_up.hip -- nn.MaxPool2d(2) (unet_parts.py:32) and nn.Upsample(scale_factor=2, 'bilinear',
+// align_corners=True) + F.pad (unet_parts.py:70,85-88) for NHWC tensors; all HBM-bound, one 16-byte
+// channel vector per lane.
+#include "uh_vec.h"
+
+static inline unsigned pu_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------ max-pool
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                           int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, G = C / V;
+    const int64_t total = (int64_t)B * Ho * Wo * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % G) * V;
+        int64_t p = idx / G;
+        int ox = (int)(p % Wo);
+        int oy = (int)((p / Wo) % Ho);
+        int b = (int)(p / ((int64_t)Wo * Ho));
+        const T* base = x + ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * ldx + c;
+        float a[V], t[V];
+        uh_load<T, V>(base, a);
+        uh_load<T, V>(base + ldx, t);
+#pragma unroll
+        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        uh_load<T, V>(base + (int64_t)W * ldx, t);
+#pragma unroll
+        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        uh_load<T, V>(base + (int64_t)W * ldx + ldx, t);
+#pragma unroll
+        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        uh_store<T, V>(y + p * ldy + c, a);
+    }
+}
+
+// dx[h,w] = dskip[h,w] + (x[h,w] is the FIRST maximum of its window in (0,0),(0,1),(1,0),(1,1) order ? dy : 0)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy,
+                                                           int lddy, const T* __restrict__ dskip, int ldskip,
+                                                           T* __restrict__ dx, int lddx, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, G = C / V;
+    const int64_t total = (int64_t)B * H * W * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % G) * V;
+        int64_t p = idx / G;
+        int w = (int)(p % W);
+        int h = (int)((p / W) % H);
+        int b = (int)(p / ((int64_t)W * H));
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = 0.f;
+        if (dskip) uh_load<T, V>(dskip + p * ldskip + c, o);
+        const int oy = h >> 1, ox = w >> 1;
+        if (oy < Ho && ox < Wo) {
+            const T* base = x + ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * ldx + c;
+            float v0[V], v1[V], v2[V], v3[V], g[V];
+            uh_load<T, V>(base, v0);
+            uh_load<T, V>(base + ldx, v1);
+            uh_load<T, V>(base + (int64_t)W * ldx, v2);
+            uh_load<T, V>(base + (int64_t)W * ldx + ldx, v3);
+            uh_load<T, V>(dy + ((int64_t)(b * Ho + oy) * Wo + ox) * lddy + c, g);
+            const int me = (h & 1) * 2 + (w & 1);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                int arg = 0;
+                float m = v0[i];
+                if (v1[i] > m) { m = v1[i]; arg = 1; }
+                if (v2[i] > m) { m = v2[i]; arg = 2; }
+                if (v3[i] > m) { m = v3[i]; arg = 3; }
+                if (arg == me) o[i] += g[i];
+            }
+        }
+        uh_store<T, V>(dx + p * lddx + c, o);
+    }
+}
+
+extern "C" int uh_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int dt,
+                               uh_stream stream) {
+    UH_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && ldx >= C && ldy >= C, "uh_maxpool2_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t npo = (int64_t)B * (H / 2) * (W / 2);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
+            hipLaunchKernelGGL((maxpool2_fwd_kernel<T, VEC>), dim3(pu_grid(npo * (C / VEC))), dim3(256), 0, st, (const T*)x,
+                               ldx, (T*)y, ldy, B, H, W, C);
+        else
+            hipLaunchKernelGGL((maxpool2_fwd_kernel<T, 1>), dim3(pu_grid(npo * C)), dim3(256), 0, st, (const T*)x, ldx,
+                               (T*)y, ldy, B, H, W, C);
+    });
+    UH_CHECK_LAUNCH("maxpool2_fwd_kernel");
+    return UH_OK;
+}
+
+extern "C" int uh_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int ldskip, void* dx,
+                               int lddx, int B, int H, int W, int C, int dt, uh_stream stream) {
+    UH_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && ldx >= C && lddy >= C && lddx >= C,
+               "uh_maxpool2_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t np = (int64_t)B * H * W;
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C) &&
+            (!dskip || uh_vec_ok<T>(dskip, ldskip, C)))
+            hipLaunchKernelGGL((maxpool2_bwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st, (const T*)x,
+                               ldx, (const T*)dy, lddy, (const T*)dskip, ldskip, (T*)dx, lddx, B, H, W, C);
+        else
+            hipLaunchKernelGGL((maxpool2_bwd_kernel<T, 1>), dim3(pu_grid(np * C)), dim3(256), 0, st, (const T*)x, ldx,
+                               (const T*)dy, lddy, (const T*)dskip, ldskip, (T*)dx, lddx, B, H, W, C);
+    });
+    UH_CHECK_LAUNCH("maxpool2_bwd_kernel");
+    return UH_OK;
+}
+
+// ------------------------------------------------------------------------------------ bilinear x2
+// PyTorch's align_corners=True rule: scale = (in-1)/(out-1) in float; src = scale*dst; i0 = (int)src;
+// i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1.
+struct UpCoord { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpCoord up_coord(int dst, float scale, int in) {
+    float src = scale * (float)dst;
+    int i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    UpCoord u;
+    u.i0 = i0;
+    u.i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    u.l1 = src - (float)i0;
+    u.l0 = 1.f - u.l1;
+    return u;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                             int B, int h, int w, int C, int Ho, int Wo, int pt, int pl,
+                                                             float sy, float sx) {
+    const int G = C / V;
+    const int64_t total = (int64_t)B * Ho * Wo * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % G) * V;
+        int64_t p = idx / G;
+        int ox = (int)(p % Wo);
+        int oy = (int)((p / Wo) % Ho);
+        int b = (int)(p / ((int64_t)Wo * Ho));
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = 0.f;
+        int uy = oy - pt, ux = ox - pl;
+        if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+            UpCoord cy = up_coord(uy, sy, h), cx = up_coord(ux, sx, w);
+            const T* r0 = x + ((int64_t)(b * h + cy.i0) * w) * ldx + c;
+            const T* r1 = x + ((int64_t)(b * h + cy.i1) * w) * ldx + c;
+            float v00[V], v01[V], v10[V], v11[V];
+            uh_load<T, V>(r0 + (int64_t)cx.i0 * ldx, v00);
+            uh_load<T, V>(r0 + (int64_t)cx.i1 * ldx, v01);
+            uh_load<T, V>(r1 + (int64_t)cx.i0 * ldx, v10);
+            uh_load<T, V>(r1 + (int64_t)cx.i1 * ldx, v11);
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                o[i] = cy.l0 * (cx.l0 * v00[i] + cx.l1 * v01[i]) + cy.l1 * (cx.l0 * v10[i] + cx.l1 * v11[i]);
+        }
+        uh_store<T, V>(y + p * ldy + c, o);
+    }
+}
+
+// gather form of the transpose: every input pixel collects from the output pixels that read it
+__device__ __forceinline__ void up_range(int i, float scale, int in, int& lo, int& hi) {
+    const int out = 2 * in;
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float up_weight(int dst, float scale, int in, int i) {
+    UpCoord u = up_coord(dst, scale, in);
+    float wgt = 0.f;
+    if (u.i0 == i) wgt += u.l0;
+    if (u.i1 == i) wgt += u.l1;
+    return wgt;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx,
+                                                             int lddx, int B, int h, int w, int C, int Ho, int Wo, int pt,
+                                                             int pl, float sy, float sx) {
+    const int G = C / V;
+    const int64_t total = (int64_t)B * h * w * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % G) * V;
+        int64_t p = idx / G;
+        int ix = (int)(p % w);
+        int iy = (int)((p / w) % h);
+        int b = (int)(p / ((int64_t)w * h));
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        int ylo, yhi, xlo, xhi;
+        up_range(iy, sy, h, ylo, yhi);
+        up_range(ix, sx, w, xlo, xhi);
+        for (int uy = ylo; uy <= yhi; ++uy) {
+            float wy = up_weight(uy, sy, h, iy);
+            int oy = uy + pt;
+            if (wy == 0.f || oy < 0 || oy >= Ho) continue;
+            for (int ux = xlo; ux <= xhi; ++ux) {
+                float wx = up_weight(ux, sx, w, ix);
+                int ox = ux + pl;
+                if (wx == 0.f || ox < 0 || ox >= Wo) continue;
+                float g[V];
+                uh_load<T, V>(dy + ((int64_t)(b * Ho + oy) * Wo + ox) * lddy + c, g);
+                float ww = wy * wx;
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] = fmaf(ww, g[i], acc[i]);
+            }
+        }
+        uh_store<T, V>(dx + p * lddx + c, acc);
+    }
+}
+
+static inline float up_scale(int in) { return (2 * in > 1) ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
+
+extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B, int h, int w, int C, int Ho, int Wo,
+                                 int pad_top, int pad_left, int dt, uh_stream stream) {
+    UH_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && C > 0 && ldx >= C && ldy >= C, "uh_upsample2x_fwd: bad args");
+    UH_REQUIRE(Ho > 0 && Wo > 0, "uh_upsample2x_fwd: bad output size");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t np = (int64_t)B * Ho * Wo;
+    float sy = up_scale(h), sx = up_scale(w);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
+            hipLaunchKernelGGL((upsample2x_fwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
+                               (const T*)x, ldx, (T*)y, ldy, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
+        else
+            hipLaunchKernelGGL((upsample2x_fwd_kernel<T, 1>), dim3(pu_grid(np * C)), dim3(256), 0, st, (const T*)x, ldx,
+                               (T*)y, ldy, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
+    });
+    UH_CHECK_LAUNCH("upsample2x_fwd_kernel");
+    return UH_OK;
+}
+
+extern "C" int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int B, int h, int w, int C, int Ho, int Wo,
+                                 int pad_top, int pad_left, int dt, uh_stream stream) {
+    UH_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && C > 0 && lddy >= C && lddx >= C, "uh_upsample2x_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t np = (int64_t)B * h * w;
+    float sy = up_scale(h), sx = up_scale(w);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C))
+            hipLaunchKernelGGL((upsample2x_bwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
+                               (const T*)dy, lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
+        else
+            hipLaunchKernelGGL((upsample2x_bwd_kernel<T, 1>), dim3(pu_grid(np * C)), dim3(256), 0, st, (const T*)dy, lddy,
+                               (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
+    });
+    UH_CHECK_LAUNCH("upsample2x_bwd_kernel");
+    return UH_OK;
+}

@@ -1,0 +1,83 @@
+// Shared device/host helpers for libunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "unet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define UH_WAVE 64
+
+// ------------------------------------------------------------------ error plumbing (host)
+void uh_set_error(const char* fmt, ...);
+#define UH_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            uh_set_error(__VA_ARGS__);                          \
+            return UH_EINVAL;                                   \
+        }                                                       \
+    } while (0)
+#define UH_CHECK_LAUNCH(name)                                                         \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            uh_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+            return UH_ELAUNCH;                                                        \
+        }                                                                             \
+    } while (0)
+
+static inline bool uh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ------------------------------------------------------------------ dtype helpers (device)
+template <typename T> struct uh_traits;
+template <> struct uh_traits<float> {
+    static constexpr int VEC = 4;   // elements per 16 bytes
+};
+template <> struct uh_traits<bf16_t> {
+    static constexpr int VEC = 8;
+};
+
+__device__ __forceinline__ float uh_bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+__device__ __forceinline__ float uh_to_f32(float v) { return v; }
+__device__ __forceinline__ float uh_to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T uh_from_f32(float v);
+template <> __device__ __forceinline__ float uh_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t uh_from_f32<bf16_t>(float v) { return (bf16_t)v; }
+// value as it will be read back from a T store
+template <typename T> __device__ __forceinline__ float uh_round_as(float v) { return uh_to_f32(uh_from_f32<T>(v)); }
+
+// 16-byte vector of T <-> floats
+template <typename T> struct uh_vec16;
+template <> struct uh_vec16<float> {
+    f32x4 v;
+    static constexpr int N = 4;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = f; }
+};
+template <> struct uh_vec16<bf16_t> {
+    bf16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+__device__ __forceinline__ float uh_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float uh_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// softplus-form BCE-with-logits term: max(x,0) - x*t + log1p(exp(-|x|))
+__device__ __forceinline__ float uh_bce_logits(float x, float t) {
+    return fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+}

@@ -1,0 +1,536 @@
+"""Torch-side plumbing over the C ABI (include/unet_hip.h): tensor descriptors -> raw pointers,
+and the torch.autograd.Function nodes that put the HIP kernels behind the reference's nn.Module
+surface.  Activations travel between nodes as pixel-dense NHWC tensors [B,H,W,C] whose pixel
+stride may exceed C (channel slices of a wider buffer); the user-facing modules expose them as
+logical NCHW views.  Everything here requires GPU tensors: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from ._lib import LIB, UH_BF16, UH_F32
+
+BN_EPS_DEFAULT = 1e-5
+
+
+# ----------------------------------------------------------------------------- helpers
+def _require_gpu(t: torch.Tensor, what: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} is on {t.device}: the HIP path needs GPU tensors (no CPU fallback exists)")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return UH_BF16
+    if t.dtype == torch.float32:
+        return UH_F32
+    raise RuntimeError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def compute_dtype(default: torch.dtype = torch.float32) -> torch.dtype:
+    """bf16 inside torch.autocast (train.py:116 wraps the forward in autocast), else `default`."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return default
+
+
+def pixel_ld(t: torch.Tensor) -> int:
+    """Pixel stride (elements) of an NHWC tensor [B,H,W,C]."""
+    B, H, W, C = t.shape
+    if W > 1:
+        return t.stride(2)
+    if H > 1:
+        return t.stride(1)
+    if B > 1:
+        return t.stride(0)
+    return max(C, 1)
+
+
+def is_pixel_dense(t: torch.Tensor) -> bool:
+    B, H, W, C = t.shape
+    if C > 1 and t.stride(3) != 1:
+        return False
+    ld = pixel_ld(t)
+    if ld < C:
+        return False
+    if W > 1 and t.stride(2) != ld:
+        return False
+    if H > 1 and t.stride(1) != W * ld:
+        return False
+    if B > 1 and t.stride(0) != H * W * ld:
+        return False
+    return True
+
+
+def dense_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` ([B,H,W,C]) if it can be walked with one pixel stride, else a packed copy."""
+    return t if is_pixel_dense(t) else t.contiguous()
+
+
+def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Logical NCHW tensor (any memory format) -> pixel-dense NHWC view/copy in `dtype`."""
+    _require_gpu(x, "input")
+    v = x.permute(0, 2, 3, 1)
+    if dtype is not None and v.dtype != dtype:
+        v = v.to(dtype)
+    return dense_nhwc(v)
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def _empty_like_param(p: torch.Tensor) -> torch.Tensor:
+    return torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=p.device)
+
+
+def _is_krsc_dense(w: torch.Tensor) -> bool:
+    O, I, kh, kw = w.shape
+    return w.stride() == (kh * kw * I, 1, kw * I, I)
+
+
+# ----------------------------------------------------------------------------- raw op wrappers
+def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool):
+    O, I = weight.shape[0], weight.shape[1]
+    w32 = weight if weight.dtype == torch.float32 else weight.float()
+    wf = torch.empty(O * 9 * I, dtype=dtype, device=weight.device)
+    wd = torch.empty(O * 9 * I, dtype=dtype, device=weight.device) if need_dgrad else None
+    sO, sI, sH, sW = w32.stride()
+    LIB.call("uh_pack_w3x3", w32.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), _p(wd),
+             UH_BF16 if dtype == torch.bfloat16 else UH_F32, _stream())
+    return wf, wd
+
+
+def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, Cout: int,
+                want_stats: bool):
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    dt = _dt(x0)
+    y = torch.empty((B, H, W, Cout), dtype=x0.dtype, device=x0.device)
+    stats, nslab = None, 0
+    if want_stats:
+        nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, C0 + C1, Cout, dt)
+        stats = torch.empty(nslab * 2 * Cout, dtype=torch.float32, device=x0.device)
+    LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
+             w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt, _stream())
+    return y, stats, nslab
+
+
+def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], out_krsc: torch.Tensor):
+    B, H, W, Cout = dy.shape
+    C0 = x0.shape[3]
+    C1 = 0 if x1 is None else x1.shape[3]
+    dt = _dt(dy)
+    nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, C0 + C1, Cout, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
+             0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
+
+
+# ----------------------------------------------------------------------------- conv + BN + ReLU
+class ConvBnReluFn(Function):
+    """(nn.Conv2d(3x3, pad 1, no bias) -> nn.BatchNorm2d -> nn.ReLU) of unet_parts.py:15-17 / 18-20 as
+    one autograd node.  Inputs: x0 (+ optional x1 = second half of the channel concat of
+    unet_parts.py:95, never materialised), the reference-layout parameters, BN buffers."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
+                training: bool, momentum: float, eps: float):
+        _require_gpu(x0, "activation")
+        x0 = dense_nhwc(x0)
+        x1 = None if x1 is None else dense_nhwc(x1)
+        B, H, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if Cin != C0 + C1:
+            raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
+        need_dx = any(ctx.needs_input_grad[:2])
+        wf, wd = pack_w3x3(weight, x0.dtype, need_dx)
+        dev = x0.device
+        coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
+        n = B * H * W
+        g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
+        b32 = beta if beta.dtype == torch.float32 else beta.float()
+        if training:
+            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True)
+            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(),
+                     _p(running_mean), _p(running_var), float(momentum), float(eps), scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+            if num_batches_tracked is not None:
+                num_batches_tracked.add_(1)
+        else:
+            y, _, _ = conv3x3_fwd(x0, x1, wf, Cout, False)
+            LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(),
+                     running_var.data_ptr(), float(eps), Cout, scale.data_ptr(), shift.data_ptr(), _stream())
+            mean.copy_(running_mean)
+            rstd.copy_(torch.rsqrt(running_var + eps))
+        z = torch.empty_like(y)
+        LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
+                 n, Cout, _dt(y), _stream())
+        ctx.save_for_backward(x0, x1, y, coef, wd, weight)
+        ctx.training = training
+        ctx.dims = (B, H, W, C0, C1, Cout)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, x1, y, coef, wd, weight = ctx.saved_tensors
+        B, H, W, C0, C1, Cout = ctx.dims
+        if not ctx.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not part of the train path")
+        Cin = C0 + C1
+        n = B * H * W
+        dev = y.device
+        dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
+        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
+        dt = _dt(y)
+        nblk = LIB.query("uh_bn_bwd_nblk", n, Cout)
+        partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
+        LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
+        dgb = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+        dgamma, dbeta = dgb[:Cout], dgb[Cout:]
+        dy = torch.empty_like(y)
+        LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
+                 dbeta.data_ptr(), dy.data_ptr(), Cout, n, Cout, dt, _stream())
+        # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
+        dweight = None
+        if ctx.needs_input_grad[2]:
+            dweight = _empty_like_param(weight)
+            if _is_krsc_dense(weight):
+                conv3x3_wgrad(dy, x0, x1, dweight)
+            else:
+                dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
+                conv3x3_wgrad(dy, x0, x1, dwk)
+                sO, sI, sH, sW = dweight.stride()
+                LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
+        dx0 = dx1 = None
+        if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False)
+            dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
+            dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
+        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- max-pool
+def _maxpool_fwd(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    LIB.call("uh_maxpool2_fwd", x.data_ptr(), pixel_ld(x), y.data_ptr(), C, B, H, W, C, _dt(x), _stream())
+    return y
+
+
+def _maxpool_bwd(x, dy, dskip):
+    B, H, W, C = x.shape
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    dy = dense_nhwc(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+    if dskip is not None:
+        dskip = dense_nhwc(dskip if dskip.dtype == x.dtype else dskip.to(x.dtype))
+    LIB.call("uh_maxpool2_bwd", x.data_ptr(), pixel_ld(x), dy.data_ptr(), pixel_ld(dy), _p(dskip),
+             0 if dskip is None else pixel_ld(dskip), dx.data_ptr(), C, B, H, W, C, _dt(x), _stream())
+    return dx
+
+
+class MaxPool2Fn(Function):
+    """nn.MaxPool2d(2) (unet_parts.py:32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "activation")
+        x = dense_nhwc(x)
+        ctx.save_for_backward(x)
+        return _maxpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _maxpool_bwd(x, dy, None)
+
+
+class PoolSplitFn(Function):
+    """x -> (x as the skip connection, maxpool(x)).  One node so that the backward adds the skip
+    gradient and routes the pooled gradient in a single pass (unet_model.py:28-32 uses every
+    encoder output twice)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "activation")
+        x = dense_nhwc(x)
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), _maxpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dskip, dpool):
+        (x,) = ctx.saved_tensors
+        if dpool is None:
+            return dskip
+        return _maxpool_bwd(x, dpool, dskip)
+
+
+# ----------------------------------------------------------------------------- upsample / convT (+ pad)
+def _pad_geometry(h, w, Ho, Wo):
+    """F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) of unet_parts.py:85-88 (Python floor division)."""
+    dY, dX = Ho - 2 * h, Wo - 2 * w
+    return dY // 2, dX // 2
+
+
+class UpsampleBilinearPadFn(Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad (unet_parts.py:70,85-88)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho: int, Wo: int):
+        _require_gpu(x, "activation")
+        x = dense_nhwc(x)
+        B, h, w, C = x.shape
+        pt, pl = _pad_geometry(h, w, Ho, Wo)
+        y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        LIB.call("uh_upsample2x_fwd", x.data_ptr(), pixel_ld(x), y.data_ptr(), C, B, h, w, C, Ho, Wo, pt, pl,
+                 _dt(x), _stream())
+        ctx.geom = (B, h, w, C, Ho, Wo, pt, pl)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, C, Ho, Wo, pt, pl = ctx.geom
+        dy = dense_nhwc(dy)
+        dx = torch.empty((B, h, w, C), dtype=dy.dtype, device=dy.device)
+        LIB.call("uh_upsample2x_bwd", dy.data_ptr(), pixel_ld(dy), dx.data_ptr(), C, B, h, w, C, Ho, Wo, pt, pl,
+                 _dt(dy), _stream())
+        return dx, None, None
+
+
+class ConvTranspose2x2PadFn(Function):
+    """nn.ConvTranspose2d(Cin, Cin//2, 2, stride=2) + F.pad (unet_parts.py:73,85-88)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, Ho: int, Wo: int):
+        _require_gpu(x, "activation")
+        x = dense_nhwc(x)
+        B, h, w, Cin = x.shape
+        Cout = weight.shape[1]
+        wc = weight.contiguous().float()
+        bc = bias.contiguous().float()
+        pt, pl = _pad_geometry(h, w, Ho, Wo)
+        y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        LIB.call("uh_convt2x2_fwd", x.data_ptr(), pixel_ld(x), wc.data_ptr(), bc.data_ptr(), y.data_ptr(), Cout,
+                 B, h, w, Cin, Cout, Ho, Wo, pt, pl, _dt(x), _stream())
+        ctx.save_for_backward(x, wc)
+        ctx.geom = (B, h, w, Cin, Cout, Ho, Wo, pt, pl)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        B, h, w, Cin, Cout, Ho, Wo, pt, pl = ctx.geom
+        dy = dense_nhwc(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+        dt = _dt(x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, h, w, Cin), dtype=x.dtype, device=x.device)
+            LIB.call("uh_convt2x2_dgrad", dy.data_ptr(), pixel_ld(dy), wc.data_ptr(), dx.data_ptr(), Cin, B, h, w,
+                     Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        nbytes = LIB.query("uh_convt2x2_wgrad_ws_bytes", B, h, w, Cin, Cout)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dw = torch.empty((Cin, Cout, 2, 2), dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        LIB.call("uh_convt2x2_wgrad", dy.data_ptr(), pixel_ld(dy), x.data_ptr(), pixel_ld(x), dw.data_ptr(),
+                 db.data_ptr(), ws.data_ptr(), nbytes, B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        return dx, dw, db, None, None
+
+
+# ----------------------------------------------------------------------------- OutConv
+class OutConv1x1Fn(Function):
+    """nn.Conv2d(Cin, n_classes, kernel_size=1) with bias (unet_parts.py:103); logits are fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, "activation")
+        x = dense_nhwc(x)
+        B, H, W, Cin = x.shape
+        ncls = weight.shape[0]
+        w2 = weight.reshape(ncls, Cin).contiguous().float()
+        b2 = bias.contiguous().float()
+        logits = torch.empty((B, H, W, ncls), dtype=torch.float32, device=x.device)
+        LIB.call("uh_conv1x1_fwd", x.data_ptr(), pixel_ld(x), w2.data_ptr(), b2.data_ptr(), logits.data_ptr(),
+                 B * H * W, Cin, ncls, _dt(x), _stream())
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = tuple(weight.shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, w2 = ctx.saved_tensors
+        B, H, W, Cin = x.shape
+        ncls = w2.shape[0]
+        n = B * H * W
+        dl = dl.float().contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, H, W, Cin), dtype=x.dtype, device=x.device)
+            LIB.call("uh_conv1x1_dgrad", dl.data_ptr(), w2.data_ptr(), dx.data_ptr(), Cin, n, Cin, ncls, _dt(x), _stream())
+        nbytes = LIB.query("uh_conv1x1_wgrad_ws_bytes", n, Cin, ncls)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dw = torch.empty((ncls, Cin), dtype=torch.float32, device=x.device)
+        db = torch.empty(ncls, dtype=torch.float32, device=x.device)
+        LIB.call("uh_conv1x1_wgrad", dl.data_ptr(), x.data_ptr(), pixel_ld(x), dw.data_ptr(), db.data_ptr(),
+                 ws.data_ptr(), nbytes, n, Cin, ncls, _dt(x), _stream())
+        return dx, dw.view(ctx.wshape), db
+
+
+# ----------------------------------------------------------------------------- losses
+def loss_workspace(device) -> torch.Tensor:
+    return torch.empty(LIB.query("uh_loss_ws_bytes", 1), dtype=torch.uint8, device=device)
+
+
+def boundary_loss_value(pred: torch.Tensor, pstride: int, bstride: int, target: torch.Tensor, B: int, H: int, W: int,
+                        edge_width: int, edge_weight: float, smooth: float = 1e-6) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws = loss_workspace(pred.device)
+    LIB.call("uh_boundary_loss", pred.data_ptr(), pstride, bstride, target.data_ptr(), B, H, W, int(edge_width),
+             float(edge_weight), float(smooth), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+class SegLossBinaryFn(Function):
+    """train.py:119-134 in one node: t = mask // mask_div; BCEWithLogits(mean) + dice_loss(sigmoid) +
+    w_boundary * boundary_loss(logits, t, 51, 15).  Returns [total, bce, dice, boundary]; only `total`
+    carries gradient (boundary_loss is constant w.r.t. the logits).
+    `reduce_sums` (optional callable) all-reduces the 4 partial sums across data-parallel ranks so the
+    Dice ratio and the BCE mean are those of the GLOBAL batch."""
+
+    @staticmethod
+    def forward(ctx, logits, mask, mask_div: int, w_boundary: float, edge_width: int, edge_weight: float,
+                reduce_sums=None, world: int = 1):
+        _require_gpu(logits, "logits")
+        lg = logits.float().contiguous()
+        if mask.dim() != 3 or lg.numel() != mask.numel():
+            raise RuntimeError(f"binary seg loss expects mask [B,H,W] matching the logits, got {tuple(mask.shape)} "
+                               f"vs {tuple(logits.shape)}")
+        B, H, W = mask.shape
+        n = lg.numel()
+        mk = mask.contiguous()
+        if mk.dtype != torch.int64:
+            mk = mk.long()
+        dev = lg.device
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = loss_workspace(dev)
+        LIB.call("uh_bce_dice_sums", lg.data_ptr(), mk.data_ptr(), int(mask_div), None, n, sums.data_ptr(),
+                 ws.data_ptr(), ws.numel(), _stream())
+        if reduce_sums is not None:
+            reduce_sums(sums)
+        bl = None
+        if w_boundary != 0.0:
+            tf = (mk // mask_div).float() if mask_div != 1 else mk.float()
+            bl = boundary_loss_value(lg, 1, H * W, tf, B, H, W, edge_width, edge_weight)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(n * world), _p(bl), float(w_boundary),
+                 out.data_ptr(), _stream())
+        ctx.save_for_backward(lg, mk, sums)
+        ctx.meta = (int(mask_div), n, world, logits.shape, logits.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, mk, sums = ctx.saved_tensors
+        mask_div, n, world, shape, dtype = ctx.meta
+        g0 = gout[0:1].contiguous().float()       # only the total carries gradient
+        dl = torch.empty_like(lg)
+        LIB.call("uh_bce_dice_grad", lg.data_ptr(), mk.data_ptr(), mask_div, None, n, sums.data_ptr(),
+                 float(n * world), 1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())
+        dl = dl.view(shape)
+        if dtype != torch.float32:
+            dl = dl.to(dtype)
+        return dl, None, None, None, None, None, None, None
+
+
+class SegLossMulticlassFn(Function):
+    """train.py:136-142: CrossEntropyLoss + dice_loss(softmax, one_hot, multiclass=True) on NHWC
+    fp32 logits [B,H,W,C] (+ optional w_boundary * boundary_loss on channel 1, train.py:143-147)."""
+
+    @staticmethod
+    def forward(ctx, logits_nhwc, mask, w_boundary: float, edge_width: int, edge_weight: float,
+                reduce_sums=None, world: int = 1):
+        _require_gpu(logits_nhwc, "logits")
+        lg = logits_nhwc.float().contiguous()
+        B, H, W, C = lg.shape
+        npix = B * H * W
+        mk = mask.contiguous()
+        if mk.dtype != torch.int64:
+            mk = mk.long()
+        dev = lg.device
+        sums = torch.empty(1 + 3 * C, dtype=torch.float32, device=dev)
+        ws = loss_workspace(dev)
+        LIB.call("uh_ce_dice_sums", lg.data_ptr(), mk.data_ptr(), npix, C, sums.data_ptr(), ws.data_ptr(),
+                 ws.numel(), _stream())
+        if reduce_sums is not None:
+            reduce_sums(sums)
+        bl = None
+        if w_boundary != 0.0:
+            # 4-D path of boundary_loss.py:20-23: channel 1 of the logits, target = mask as float
+            bl = boundary_loss_value(lg[..., 1], C, H * W * C, mk.float(), B, H, W, edge_width, edge_weight)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        LIB.call("uh_seg_loss_multiclass_finish", sums.data_ptr(), C, float(npix * world), _p(bl),
+                 float(w_boundary), out.data_ptr(), _stream())
+        ctx.save_for_backward(lg, mk, sums)
+        ctx.meta = (npix, C, world, logits_nhwc.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, mk, sums = ctx.saved_tensors
+        npix, C, world, dtype = ctx.meta
+        g0 = gout[0:1].contiguous().float()
+        dl = torch.empty_like(lg)
+        LIB.call("uh_ce_dice_grad", lg.data_ptr(), mk.data_ptr(), npix, C, sums.data_ptr(), float(npix * world),
+                 1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())
+        if dtype != torch.float32:
+            dl = dl.to(dtype)
+        return dl, None, None, None, None, None, None
+
+
+class DiceCoeffFn(Function):
+    """dice_coeff (dice_score.py:5-25) over `ngroups` groups of `group_len` elements."""
+
+    @staticmethod
+    def forward(ctx, x, t, ngroups: int, group_len: int, eps: float):
+        _require_gpu(x, "input")
+        xf = x.float().contiguous()
+        tf = t.float().contiguous()
+        dev = xf.device
+        sums = torch.empty(ngroups * 3, dtype=torch.float32, device=dev)
+        ws = loss_workspace(dev)
+        LIB.call("uh_dice_sums", xf.data_ptr(), tf.data_ptr(), ngroups, group_len, sums.data_ptr(), ws.data_ptr(),
+                 ws.numel(), _stream())
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        LIB.call("uh_dice_from_sums", sums.data_ptr(), ngroups, float(eps), out.data_ptr(), _stream())
+        ctx.save_for_backward(tf, sums)
+        ctx.meta = (ngroups, group_len, eps, x.shape, x.dtype)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        tf, sums = ctx.saved_tensors
+        ngroups, group_len, eps, shape, dtype = ctx.meta
+        s = sums.view(ngroups, 3)
+        inter2 = 2 * s[:, 0]
+        sets = s[:, 1] + s[:, 2]
+        live = sets != 0
+        den = sets + eps
+        ka = torch.where(live, 2.0 / den, torch.zeros_like(den))
+        kb = torch.where(live, -(inter2 + eps) / (den * den), torch.zeros_like(den))
+        dx = (ka[:, None] * tf.view(ngroups, group_len) + kb[:, None]) * (g / ngroups)
+        return dx.view(shape).to(dtype), None, None, None, None

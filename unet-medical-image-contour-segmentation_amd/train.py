@@ -1,0 +1,221 @@
+"""The optimizer step of /root/reference/train.py:113-159 on the HIP path.
+
+    seg_loss(...)     loss assembly of train.py:118-142 (fused single-pass kernels)
+    FusedRMSprop      clip_grad_norm_(1.0) + RMSprop(lr, weight_decay=1e-8, momentum=0.999) of
+                      train.py:80-81,157-158 as two passes over one flat fp32 buffer
+    train_step(...)   zero_grad -> forward (autocast) -> loss -> NaN check -> backward -> clip -> step
+    TrainStepper      model + optimizer (+ data-parallel sync) bundle used by bench.py
+    train_model(...)  the epoch loop of train.py:29-220 on a user-supplied iterable of batches
+A reference-style loop with torch.optim.RMSprop / clip_grad_norm_ on `model.parameters()` also
+works unchanged: the modules are ordinary nn.Modules.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from . import dp as dpmod
+from . import ops
+from ._lib import LIB
+
+
+# ----------------------------------------------------------------------------------- loss
+def seg_loss(masks_pred: torch.Tensor, true_masks: torch.Tensor, n_classes: int, *, reduce_sums=None, world: int = 1,
+             boundary_weight: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """train.py:118-142.  masks_pred: logits [B,n_classes,H,W] (as returned by the model);
+    true_masks: int64 [B,H,W] with the dataset's values {0,1,2,..} (NOT yet // 2)."""
+    if n_classes == 1:
+        w_b = 0.25 if boundary_weight is None else boundary_weight          # train.py:134
+        lg = masks_pred.squeeze(1)
+        out = ops.SegLossBinaryFn.apply(lg, true_masks, 2, w_b, 51, 15.0, reduce_sums, world)
+        return {"loss": out[0], "bce": out[1].detach(), "dice": out[2].detach(), "boundary": out[3].detach()}
+    w_b = 0.0 if boundary_weight is None else boundary_weight               # train.py:143-147 is commented out
+    lg = masks_pred.permute(0, 2, 3, 1)
+    out = ops.SegLossMulticlassFn.apply(lg, true_masks, w_b, 51, 7.0, reduce_sums, world)
+    return {"loss": out[0], "ce": out[1].detach(), "dice": out[2].detach(), "boundary": out[3].detach()}
+
+
+# ----------------------------------------------------------------------------------- optimizer
+class FusedRMSprop:
+    """clip_grad_norm_ + torch.optim.RMSprop(momentum > 0, centered=False) over ONE flat buffer.
+
+    Every parameter is re-pointed at a view of `flat_p` (values preserved, strides preserved, so
+    channels_last weights stay channels_last); gradients are gathered into `flat_g` by
+    post-accumulate hooks in backward-ready order, which is also the bucket order of the
+    data-parallel all-reduce."""
+
+    def __init__(self, params: Iterable[nn.Parameter], lr: float = 1e-5, alpha: float = 0.99, eps: float = 1e-8,
+                 weight_decay: float = 1e-8, momentum: float = 0.999, gradient_clipping: float = 1.0,
+                 process_group=None, bucket_bytes: int = 8 << 20):
+        plist = [p for p in params if p.requires_grad]
+        if not plist:
+            raise ValueError("FusedRMSprop got no parameters")
+        dev = plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedRMSprop needs parameters on the GPU (no CPU fallback)")
+        self.params = list(reversed(plist))          # backward produces gradients roughly in this order
+        self.defaults = dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=momentum)
+        self.param_groups = [dict(self.defaults, params=self.params)]
+        self.gradient_clipping = float(gradient_clipping) if gradient_clipping else 0.0
+        slices, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            slices.append((off, n))
+            off += (n + 3) // 4 * 4                  # keep every slice 16-byte aligned
+        self.total = off
+        self.slices = slices
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_buf = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(LIB.query("uh_optim_ws_bytes", off), dtype=torch.uint8, device=dev)
+        self._index = {}
+        with torch.no_grad():
+            for i, (p, (o, n)) in enumerate(zip(self.params, slices)):
+                if p.dtype != torch.float32:
+                    raise RuntimeError("FusedRMSprop expects fp32 master parameters")
+                view = torch.as_strided(self.flat_p, p.shape, p.stride(), o)
+                if not _is_dense(p):
+                    raise RuntimeError("parameters must be dense (contiguous or channels_last)")
+                view.copy_(p)
+                p.data = view
+                self._index[id(p)] = i
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self.sync = None
+        if dpmod.world_size(process_group) > 1:
+            self.sync = dpmod.BucketedGradSync(self.flat_g, slices, bucket_bytes, process_group)
+
+    def _on_grad(self, p: torch.Tensor):
+        i = self._index[id(p)]
+        o, n = self.slices[i]
+        g = p.grad
+        dst = torch.as_strided(self.flat_g, p.shape, p.stride(), o)
+        dst.copy_(g)
+        p.grad = None
+        if self.sync is not None:
+            self.sync.mark_ready(i)
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        if self.sync is not None:
+            self.sync.wait()
+        g = self.param_groups[0]
+        st = torch.cuda.current_stream().cuda_stream
+        LIB.call("uh_grad_sumsq", self.flat_g.data_ptr(), self.total, self.norm.data_ptr(), self.ws.data_ptr(),
+                 self.ws.numel(), st)
+        LIB.call("uh_rmsprop_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_sq.data_ptr(),
+                 self.flat_buf.data_ptr(), self.total, self.norm.data_ptr(), self.gradient_clipping, float(g["lr"]),
+                 float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]), st)
+        return self.norm
+
+    def grad_of(self, p: torch.Tensor) -> torch.Tensor:
+        """The (clipped, after step()) gradient of `p` as stored in the flat buffer."""
+        o, n = self.slices[self._index[id(p)]]
+        return torch.as_strided(self.flat_g, p.shape, p.stride(), o)
+
+
+def _is_dense(p: torch.Tensor) -> bool:
+    sizes_strides = sorted(((st, sz) for sz, st in zip(p.shape, p.stride()) if sz > 1))
+    expect = 1
+    for st, sz in sizes_strides:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+# ----------------------------------------------------------------------------------- one step
+def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: torch.Tensor, *, amp: bool = True,
+               gradient_clipping: float = 1.0, reduce_sums=None, world: int = 1, check_nan: bool = True,
+               boundary_weight: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """Statement sequence of train.py:113-159.  `optimizer` is a FusedRMSprop (clipping fused into
+    its step) or any torch.optim optimizer (then clip_grad_norm_ is applied as in the reference)."""
+    assert images.shape[1] == model.n_channels, \
+        f"Network has been defined with {model.n_channels} input channels, but loaded images have " \
+        f"{images.shape[1]} channels. Please check that the images are loaded correctly."   # train.py:108-111
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        masks_pred = model(images)
+        terms = seg_loss(masks_pred, true_masks, model.n_classes, reduce_sums=reduce_sums, world=world,
+                         boundary_weight=boundary_weight)
+    loss = terms["loss"]
+    if check_nan and bool(torch.isnan(loss).any()):
+        raise RuntimeError("Fatal: NaN loss detected!")                                       # train.py:149-151
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if isinstance(optimizer, FusedRMSprop):
+        terms["grad_norm"] = optimizer.step()
+    else:
+        terms["grad_norm"] = torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clipping)
+        optimizer.step()
+    terms["logits"] = masks_pred.detach()
+    return terms
+
+
+class TrainStepper:
+    """Model + FusedRMSprop (+ RCCL gradient sync when torch.distributed is initialised)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
+                 gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True):
+        self.model = model
+        self.amp = amp
+        self.check_nan = check_nan
+        self.group = process_group
+        self.world = dpmod.world_size(process_group)
+        self.reduce_sums = dpmod.make_sum_reducer(process_group)
+        self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
+                                      gradient_clipping=gradient_clipping, process_group=process_group)
+
+    def step(self, images, true_masks):
+        self.model.train()
+        return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
+                          reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan)
+
+
+# ----------------------------------------------------------------------------------- epoch loop
+def cosine_warm_restarts_lr(base_lr: float, epoch_arg: float, T_0: int = 4, T_mult: int = 2, eta_min: float = 1e-7):
+    """CosineAnnealingWarmRestarts.step(epoch) closed form; train.py:187 passes the Dice score as
+    `epoch` -- reproduced, not fixed."""
+    e = float(epoch_arg)
+    if e >= T_0:
+        n = int(math.log(e / T_0 * (T_mult - 1) + 1, T_mult)) if T_mult > 1 else int(e // T_0)
+        T_cur = e - T_0 * (T_mult ** n - 1) / (T_mult - 1) if T_mult > 1 else e % T_0
+        T_i = T_0 * T_mult ** n
+    else:
+        T_cur, T_i = e, T_0
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * T_cur / T_i)) / 2
+
+
+def train_model(model, device, train_batches, val_batches=None, epochs: int = 5, learning_rate: float = 1e-5,
+                amp: bool = True, weight_decay: float = 1e-8, momentum: float = 0.999,
+                gradient_clipping: float = 1.0, log=None):
+    """Epoch loop of train.py:29-220 over in-memory iterables of {'image','mask'} batches (the
+    reference's directory dataset / checkpoint cadence / tqdm are outside the hot-path scope)."""
+    from .evaluate import evaluate
+    stepper = TrainStepper(model, lr=learning_rate, weight_decay=weight_decay, momentum=momentum,
+                           gradient_clipping=gradient_clipping, amp=amp)
+    history = []
+    for epoch in range(1, epochs + 1):
+        epoch_loss = 0.0
+        for batch in train_batches:
+            images = batch["image"].to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
+            true_masks = batch["mask"].to(device=device, dtype=torch.long)
+            terms = stepper.step(images, true_masks)
+            epoch_loss += terms["loss"].item()                                                # train.py:163
+        rec = {"epoch": epoch, "loss": epoch_loss}
+        if val_batches is not None:
+            val_score, _, min_score = evaluate(model, val_batches, device, amp, postprocess=False)
+            lr = cosine_warm_restarts_lr(learning_rate, float(val_score))                     # train.py:187
+            stepper.optimizer.param_groups[0]["lr"] = lr
+            rec.update(val_dice=float(val_score), min_dice=float(min_score), lr=lr)
+        history.append(rec)
+        if log:
+            log(rec)
+    return history

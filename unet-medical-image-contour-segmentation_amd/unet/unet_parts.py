@@ -1,0 +1,118 @@
+"""UNet building blocks on the MI355X HIP kernels.
+
+Drop-in surface of /root/reference/unet/unet_parts.py (constructor signatures, forward signatures,
+sub-module attribute names and therefore state_dict keys -- SURVEY.md A.1):
+
+    DoubleConv(in_channels, out_channels, mid_channels=None)      unet_parts.py:7-24
+    Down(in_channels, out_channels)                               unet_parts.py:26-37
+    Up(in_channels, out_channels, bilinear=True)                  unet_parts.py:62-98
+    OutConv(in_channels, out_channels)                            unet_parts.py:100-106
+
+The nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d children are PARAMETER CONTAINERS only (same
+init, same keys, visible to optimizers / state_dict / .to()); their torch forward is never called.
+Each block's forward enqueues the hand-written kernels of csrc/ through ops.py.  Public forward
+takes and returns logical NCHW tensors like the reference; `nhwc()` methods are the internal
+channels-last entry points UNet.forward chains without layout round trips.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool):
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return ops.ConvBnReluFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked, training, momentum, bn.eps)
+
+
+class DoubleConv(nn.Module):
+    """(conv3x3 -> BatchNorm -> ReLU) twice; the second input `x1` (optional) is the up-sampled half of
+    the skip concatenation, read in place by the first conv (torch.cat is never materialised)."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        mid = mid_channels if mid_channels else out_channels
+        layers = [
+            nn.Conv2d(in_channels, mid, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        ]
+        self.double_conv = nn.Sequential(*layers)
+
+    def nhwc(self, x0, x1=None):
+        seq = self.double_conv
+        h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training)
+        return _conv_bn_relu(h, None, seq[3], seq[4], self.training)
+
+    def forward(self, x):
+        return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
+
+
+class Down(nn.Module):
+    """MaxPool2d(2) then DoubleConv."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+    def nhwc(self, x):
+        return self.maxpool_conv[1].nhwc(ops.MaxPool2Fn.apply(x))
+
+    def nhwc_with_skip(self, x):
+        """-> (x for the skip connection, block output); one backward pass sums both gradients of x."""
+        skip, pooled = ops.PoolSplitFn.apply(x)
+        return skip, self.maxpool_conv[1].nhwc(pooled)
+
+    def forward(self, x):
+        return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
+
+
+class Up(nn.Module):
+    """Upsample (bilinear x2, align_corners=True | ConvTranspose2d k2 s2), zero-pad to the skip's size,
+    concat [skip, up] on channels, DoubleConv."""
+
+    def __init__(self, in_channels, out_channels, bilinear=True, use_attention=False):
+        super().__init__()
+        if use_attention:
+            raise NotImplementedError("SpatialAttention (UNet_SA only) is outside the hot-path scope (SURVEY.md section 2)")
+        self.bilinear = bool(bilinear)
+        if self.bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels)
+        self.use_attention = False
+        self.attention = nn.Identity()
+
+    def nhwc(self, x1, x2):
+        Ho, Wo = x2.shape[1], x2.shape[2]
+        if self.bilinear:
+            u = ops.UpsampleBilinearPadFn.apply(x1, Ho, Wo)
+        else:
+            u = ops.ConvTranspose2x2PadFn.apply(x1, self.up.weight, self.up.bias, Ho, Wo)
+        return self.conv.nhwc(x2, u)          # channel order [skip, up] as unet_parts.py:95
+
+    def forward(self, x1, x2):
+        dt = ops.compute_dtype(x1.dtype if x1.dtype == torch.bfloat16 else torch.float32)
+        return ops.to_nchw(self.nhwc(ops.to_nhwc(x1, dt), ops.to_nhwc(x2, dt)))
+
+
+class OutConv(nn.Module):
+    """1x1 convolution with bias; logits are returned in fp32."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def nhwc(self, x):
+        return ops.OutConv1x1Fn.apply(x, self.conv.weight, self.conv.bias)
+
+    def forward(self, x):
+        return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
