@@ -49,9 +49,11 @@ int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int
 /* ---- nn.Conv2d(k=3, padding=1, bias=False)  (unet_parts.py:15,18) --------------------------
  * y[b,h,w,o] = sum_{r,s,i} x[b,h+r-1,w+s-1,i] * w[o][r][s][i]; the input is the virtual channel
  * concat of (x0:C0) and (x1:C1) (x1 may be NULL with C1 = 0).
- * stat_partials (may be NULL): [uh_conv3x3_stat_slabs()][2][Cout] fp32, per-slab sum and sum of
- * squares of the stored y over the slab's pixels -- BatchNorm2d batch statistics
- * (unet_parts.py:16,19) without a second pass.  With w = w_dgrad this is conv backward-data. */
+ * stat_partials (may be NULL): nslab = uh_conv3x3_stat_slabs(); fp32 [nslab][2][Cout] per-slab
+ * (mean, M2 = sum (y - mean)^2) of the STORED y over the slab's pixels, then [nslab] pixel counts,
+ * then [nslab] scratch for uh_bn_finalize: nslab*(2*Cout + 2) floats.  These are BatchNorm2d's batch
+ * statistics (unet_parts.py:16,19) without a second pass over y.  With w = w_dgrad this is conv
+ * backward-data. */
 int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int dt);
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
@@ -63,7 +65,7 @@ int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
                      void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
 
 /* ---- nn.BatchNorm2d + nn.ReLU(inplace)  (unet_parts.py:16-17,19-20) ------------------------
- * finalize: reduce the conv's stat slabs -> mean, rstd = 1/sqrt(var_biased + eps),
+ * finalize: merge the conv's stat slabs (Chan's formula, double) -> mean, rstd = 1/sqrt(var_biased + eps),
  * scale = gamma*rstd, shift = beta - mean*scale; running stats (may be NULL) updated in place with
  * `momentum` and the UNBIASED variance (n = pixels per channel). */
 int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,

@@ -10,43 +10,63 @@
 #include "uh_vec.h"
 
 // ------------------------------------------------------------------------------------ finalize
-// fold: slabs [nslab][2][C] -> in place, entry f*L holds the sum of slabs [f*L, min((f+1)*L, nslab))
+// Slab layout written by the conv epilogue: [nslab][2][C] = per-tile (mean, M2) of the stored y, followed
+// by [nslab] pixel counts.  Tiles are merged with Chan's parallel-variance formula in double.
+struct Moments { double n, mean, m2; };
+__device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, double m2b) {
+    if (nb <= 0.0) return;
+    double n = a.n + nb;
+    double d = mb - a.mean;
+    a.mean += d * (nb / n);
+    a.m2 += m2b + d * d * (a.n * nb / n);
+    a.n = n;
+}
+
+// fold: in place, entry f*L <- merge of slabs [f*L, min((f+1)*L, nslab))
 __global__ __launch_bounds__(256) void bn_stats_fold_kernel(float* __restrict__ stats, int nslab, int C, int L) {
-    __shared__ float red[2][4][64];
+    __shared__ double red[3][4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int f = blockIdx.y;
     const int s0 = f * L, s1 = min(s0 + L, nslab);
-    float a = 0.f, b = 0.f;
+    const float* cnt = stats + (int64_t)nslab * 2 * C;
+    Moments m = {0.0, 0.0, 0.0};
     if (c < C)
-        for (int s = s0 + sl; s < s1; s += 4) {
-            a += stats[((int64_t)s * 2 + 0) * C + c];
-            b += stats[((int64_t)s * 2 + 1) * C + c];
-        }
-    red[0][sl][cl] = a;
-    red[1][sl][cl] = b;
+        for (int s = s0 + sl; s < s1; s += 4)
+            chan_merge(m, (double)cnt[s], (double)stats[((int64_t)s * 2 + 0) * C + c], (double)stats[((int64_t)s * 2 + 1) * C + c]);
+    red[0][sl][cl] = m.n; red[1][sl][cl] = m.mean; red[2][sl][cl] = m.m2;
     __syncthreads();
-    if (sl == 0 && c < C) {
-        stats[((int64_t)s0 * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        stats[((int64_t)s0 * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (sl == 0) {
+        for (int k = 1; k < 4; ++k) chan_merge(m, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
+        if (c < C) {
+            stats[((int64_t)s0 * 2 + 0) * C + c] = (float)m.mean;
+            stats[((int64_t)s0 * 2 + 1) * C + c] = (float)m.m2;
+        }
+    }
+    __syncthreads();
+    // counts are shared by all channels: the block with blockIdx.x == 0 folds them AFTER every thread of
+    // THIS block has read them; other channel blocks may still be reading -> write to a shadow slot
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double n = 0.0;
+        for (int s = s0; s < s1; ++s) n += (double)cnt[s];
+        stats[(int64_t)nslab * 2 * C + nslab + f] = (float)n;       // folded counts live after the raw counts
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nfold, int L, int C, double n,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int nfold, int L, int C, double n,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
                                    float* __restrict__ rstd_o) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int f = 0; f < nfold; ++f) {
-        s1 += (double)stats[((int64_t)f * L * 2 + 0) * C + c];
-        s2 += (double)stats[((int64_t)f * L * 2 + 1) * C + c];
-    }
-    double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
+    const float* cnt = stats + (int64_t)nslab * 2 * C + (L > 1 ? nslab : 0);
+    Moments m = {0.0, 0.0, 0.0};
+    for (int f = 0; f < nfold; ++f)
+        chan_merge(m, (double)cnt[f], (double)stats[((int64_t)f * L * 2 + 0) * C + c],
+                   (double)stats[((int64_t)f * L * 2 + 1) * C + c]);
+    double mean = m.mean;
+    double var = m.m2 / n;                      // biased
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma[c], bt = beta[c];
     float sc = g * rstd;
@@ -56,7 +76,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nfold, i
     rstd_o[c] = rstd;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) {
-        double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        double unb = n > 1.0 ? m.m2 / (n - 1.0) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
 }
@@ -75,8 +95,8 @@ extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int6
                            nslab, C, L);
         UH_CHECK_LAUNCH("bn_stats_fold_kernel");
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stat_partials, nfold, L, C, (double)n,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stat_partials, nslab, nfold, L, C,
+                       (double)n, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
     return UH_OK;
 }

@@ -205,11 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
     }
 
     // ---- epilogue: acc[i][n][j] = y[pixel (row wm*8+i, col lx)][channel co_base + n*16 + kg*4 + j]
-    float ssum[NB][4], ssq[NB][4];
+    // BatchNorm statistics per tile and channel as (mean, M2 = sum (v - mean)^2) of the STORED values:
+    // two passes over the accumulator registers, combined across tiles with Chan's formula in
+    // uh_bn_finalize (sum / sum-of-squares would cancel catastrophically when mean^2 >> var).
+    float ssum[NB][4];
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[n][j] = 0.f; ssq[n][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) ssum[n][j] = 0.f;
     const int gx = x0p + lx;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -218,54 +221,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
         T* yp = y + (int64_t)((b * H + gy) * W + gx) * ldy + co_base + kg * 4;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-            float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = uh_round_as<T>(acc[i][n][j]);
-                float m = ok ? v[j] : 0.f;
-                ssum[n][j] += m;
-                ssq[n][j] += m * m;
+                acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
+                ssum[n][j] += ok ? acc[i][n][j] : 0.f;
             }
             if (ok) {
                 if constexpr (ES == 2) {
-                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
                     *reinterpret_cast<bf16x4*>(yp + n * 16) = o;
                 } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(yp + n * 16) = o;
+                    *reinterpret_cast<f32x4*>(yp + n * 16) = acc[i][n];
                 }
             }
         }
     }
     if (stats) {
-        // reduce over the 16 pixel lanes (lx); kg stays
+        float* red = reinterpret_cast<float*>(lds);   // [2 wm][BN] then [BN] means; main loop ended with a barrier
+        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        const float inv_cnt = 1.f / (float)(vy * vx);
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    ssum[n][j] += __shfl_xor(ssum[n][j], o, 64);
-                    ssq[n][j] += __shfl_xor(ssq[n][j], o, 64);
-                }
-            }
-        float* red = reinterpret_cast<float*>(lds);   // [2 wm][2][BN]; main loop ended with a barrier
+                for (int o = 8; o > 0; o >>= 1) ssum[n][j] += __shfl_xor(ssum[n][j], o, 64);
         if (lx == 0) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int ch = wn * (NB * 16) + n * 16 + kg * 4 + j;
-                    red[(wm * 2 + 0) * BN + ch] = ssum[n][j];
-                    red[(wm * 2 + 1) * BN + ch] = ssq[n][j];
-                }
+                for (int j = 0; j < 4; ++j) red[wm * BN + wn * (NB * 16) + n * 16 + kg * 4 + j] = ssum[n][j];
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            int which = tid / BN, ch = tid - which * BN;
-            float v = red[(0 * 2 + which) * BN + ch] + red[(1 * 2 + which) * BN + ch];
-            stats[((int64_t)blockIdx.x * 2 + which) * Cout + co_blk + ch] = v;
+        if (tid < BN) red[2 * BN + tid] = (red[tid] + red[BN + tid]) * inv_cnt;     // tile mean
+        __syncthreads();
+        float sm2[NB][4];
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mu = red[2 * BN + wn * (NB * 16) + n * 16 + kg * 4 + j];
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (y0 + wm * 8 + i < H) && (gx < W);
+                    float d = acc[i][n][j] - mu;
+                    a += ok ? d * d : 0.f;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                sm2[n][j] = a;
+            }
+        __syncthreads();
+        if (lx == 0) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wm * BN + wn * (NB * 16) + n * 16 + kg * 4 + j] = sm2[n][j];
         }
+        __syncthreads();
+        if (tid < BN) {
+            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + co_blk + tid] = red[2 * BN + tid];
+            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + co_blk + tid] = red[tid] + red[BN + tid];
+        }
+        if (blockIdx.y == 0 && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
     }
 }
 
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem(const T* __restrict__ x,
                                                         float* __restrict__ stats, int B, int H, int W, int tilesX,
                                                         int tilesY) {
     __shared__ float xs[HALO_PIX * 4];
-    __shared__ float red[4 * 2 * 64];
+    __shared__ float red[4 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
     const int txt = t % tilesX; t /= tilesX;
@@ -304,43 +323,47 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem(const T* __restrict__ x,
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
                 wr[tap * 4 + ci] = (cok && ci < Cin) ? uh_to_f32(w[((int64_t)co * 9 + tap) * Cin + ci]) : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-        for (int rr = 0; rr < 4; ++rr) {
-            const int ty = wave * 4 + rr;
-            const int gy = y0 + ty;
-            if (gy >= H) break;
-            for (int tx = 0; tx < TILE; ++tx) {
-                const int gx = x0p + tx;
-                if (gx >= W) break;
-                float a = 0.f;
+        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        float mu = 0.f;
+        for (int pass = 0; pass < (stats ? 2 : 1); ++pass) {
+            float s1 = 0.f;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int ty = wave * 4 + rr;
+                const int gy = y0 + ty;
+                if (gy >= H) break;
+                for (int tx = 0; tx < TILE; ++tx) {
+                    const int gx = x0p + tx;
+                    if (gx >= W) break;
+                    float a = 0.f;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const float* xp = &xs[((ty + r) * HALO_W + tx + s) * 4];
+                        for (int s = 0; s < 3; ++s) {
+                            const float* xp = &xs[((ty + r) * HALO_W + tx + s) * 4];
 #pragma unroll
-                        for (int ci = 0; ci < 4; ++ci) a = fmaf(xp[ci], wr[(r * 3 + s) * 4 + ci], a);
+                            for (int ci = 0; ci < 4; ++ci) a = fmaf(xp[ci], wr[(r * 3 + s) * 4 + ci], a);
+                        }
+                    T o = uh_from_f32<T>(a);
+                    float v = uh_to_f32(o);
+                    if (cok) {
+                        if (pass == 0) { y[(int64_t)((b * H + gy) * W + gx) * ldy + co] = o; s1 += v; }
+                        else s1 += (v - mu) * (v - mu);
                     }
-                T o = uh_from_f32<T>(a);
-                float v = uh_to_f32(o);
-                if (cok) {
-                    y[(int64_t)((b * H + gy) * W + gx) * ldy + co] = o;
-                    s1 += v; s2 += v * v;
+                }
+            }
+            if (stats) {
+                __syncthreads();
+                red[wave * 64 + lane] = s1;
+                __syncthreads();
+                float tot = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+                if (pass == 0) mu = tot / (float)(vy * vx);
+                else if (wave == 0 && cok) {
+                    stats[((int64_t)blockIdx.x * 2 + 0) * Cout + co] = mu;
+                    stats[((int64_t)blockIdx.x * 2 + 1) * Cout + co] = tot;
                 }
             }
         }
-        if (stats) {
-            red[(wave * 2 + 0) * 64 + lane] = s1;
-            red[(wave * 2 + 1) * 64 + lane] = s2;
-            __syncthreads();
-            if (tid < 128) {
-                int which = tid >> 6, l = tid & 63;
-                float v = red[(0 * 2 + which) * 64 + l] + red[(1 * 2 + which) * 64 + l] + red[(2 * 2 + which) * 64 + l] +
-                          red[(3 * 2 + which) * 64 + l];
-                if (cg + l < Cout) stats[((int64_t)blockIdx.x * 2 + which) * Cout + cg + l] = v;
-            }
-            __syncthreads();
-        }
+        if (stats && cg == 0 && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
     }
 }
 
@@ -388,16 +411,21 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const T* __restrict__ y
     const int tyt = t % tilesY;
     const int b = t / tilesY;
     const int y0 = tyt * TILE, x0p = txt * TILE;
+    const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
     for (int c = threadIdx.x; c < C; c += 256) {
         float s1 = 0.f, s2 = 0.f;
-        for (int ty = 0; ty < TILE && y0 + ty < H; ++ty)
-            for (int tx = 0; tx < TILE && x0p + tx < W; ++tx) {
-                float v = uh_to_f32(y[(int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + c]);
-                s1 += v; s2 += v * v;
+        for (int ty = 0; ty < vy; ++ty)
+            for (int tx = 0; tx < vx; ++tx) s1 += uh_to_f32(y[(int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + c]);
+        const float mu = s1 / (float)(vy * vx);
+        for (int ty = 0; ty < vy; ++ty)
+            for (int tx = 0; tx < vx; ++tx) {
+                float d = uh_to_f32(y[(int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + c]) - mu;
+                s2 += d * d;
             }
-        stats[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
+        stats[((int64_t)blockIdx.x * 2 + 0) * C + c] = mu;
         stats[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
     }
+    if (threadIdx.x == 0) stats[(int64_t)gridDim.x * 2 * C + blockIdx.x] = (float)(vy * vx);
 }
 
 // =====================================================================================

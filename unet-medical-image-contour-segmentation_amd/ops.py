@@ -121,7 +121,7 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
     stats, nslab = None, 0
     if want_stats:
         nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, C0 + C1, Cout, dt)
-        stats = torch.empty(nslab * 2 * Cout, dtype=torch.float32, device=x0.device)
+        stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=x0.device)
     LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
              w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt, _stream())
     return y, stats, nslab
