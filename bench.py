@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Benchmark of the UNet segmentation train step (BASELINE.json metric: images/sec of one train step,
+UNet 1x512x512 -> 1).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = train.py:113-159 of the reference on one resident synthetic batch: forward (bf16 activations,
+fp32 accumulate / statistics / master weights), BCE + Dice + 0.25*boundary loss, NaN check, backward,
+(RCCL gradient all-reduce when N > 1), clip_grad_norm_(1.0), RMSprop.  N = 1 runs BASELINE config 2
+(UNet(1,1,bilinear=True), batch 8); N > 1 keeps 8 images per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic work (measured by hooks on the reference model): conv FLOPs per 512x512 image
+FWD_GFLOP_PER_IMAGE = {True: 319.237, False: 384.735}      # keyed by `bilinear`
+TRAIN_GFLOP_PER_IMAGE = {True: 957.41, False: 1153.90}     # fwd + dgrad + wgrad - dgrad(stem)
+MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity path) instead of bf16")
+    ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int):
+    """The CPU oracle (oracle/step_ref.py: stock fp32 PyTorch restatement of train.py:113-159, pinned to the
+    reference's golden fixtures) timed on this host: BASELINE config 1 = batch 2, 1x512x512, fp32."""
+    from oracle import step_ref as S
+    from oracle import unet_ref as U
+    torch.manual_seed(0)
+    st = U.init_state(1, 1, True, seed=0)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(2, 1, size, size, generator=g)
+    masks = torch.randint(0, 3, (2, size, size), generator=g)
+    opt = None
+    st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True)      # warm-up
+    best = float("inf")
+    nsteps = 2
+    for _ in range(nsteps):
+        t0 = time.perf_counter()
+        st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(2.0 / best, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"oracle/step_ref.train_step, UNet(1,1,bilinear=True) fp32, batch 2 x 1x{size}x{size}, "
+                      f"1 warm-up + best of {nsteps} steps ({best:.2f} s/step)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the train-step path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import unet_amd
+    from unet_amd import ops
+
+    bilinear = not args.convt
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=bilinear).to(memory_format=torch.channels_last).to(dev)
+    amp = not args.fp32
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp)
+    g = torch.Generator().manual_seed(1 + rank)
+    B, S = args.batch, args.size
+    images = torch.rand(B, 1, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    masks = torch.randint(0, 3, (B, S, S), generator=g).to(dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = stepper.step(images, masks)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = stepper.step(images, masks)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(last["loss"])
+
+    # ---- dominant-kernel roofline, measured live with events on the launch stream (one extra step)
+    roof = None
+    kernels = None
+    if rank == 0 and not args.no_kernel_profile:
+        ops.PROFILE.clear()
+        ops.PROFILE_ON = True
+        stepper.step(images, masks)
+        torch.cuda.synchronize()
+        ops.PROFILE_ON = False
+        agg = {}
+        for name, flops, e0, e1 in ops.PROFILE:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += flops
+        kernels = {k: {"calls": v[0], "ms": round(v[1] * 1e3, 3), "tflops": round(v[2] / v[1] / 1e12, 1) if v[1] > 0 else 0.0}
+                   for k, v in agg.items()}
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        peak = MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS
+        ach = dom[1][2] / dom[1][1] / 1e12
+        roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None,
+                "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
+        # the layer the north-star names: the 256-channel DoubleConv (down2: 128->256->256 at 128x128, batch 8)
+        kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
+
+    if rank == 0:
+        ips = world * B * args.steps / elapsed
+        out = {
+            "metric": "images/sec (train step) UNet 1x512x512->1",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
+            "config": {"workload": f"UNet(1,1,bilinear={bilinear}) train step (BCE+Dice+0.25*boundary, clip 1.0, RMSprop), "
+                                   f"{B} x 1x{S}x{S} per GPU, global batch {B * world}",
+                       "parallelism": f"dp{world}", "global_batch": B * world, "per_gpu_batch": B,
+                       "bn": "per-rank batch statistics", "dice": "global-batch sums (all-reduced)"},
+            "loss": round(loss, 6),
+            "train_tflops_per_gpu": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3, 1),
+            "conv_roofline_frac_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3 /
+                                             (MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS), 4),
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

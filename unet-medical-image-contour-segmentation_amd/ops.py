@@ -15,6 +15,35 @@ from ._lib import LIB, UH_BF16, UH_F32
 
 BN_EPS_DEFAULT = 1e-5
 
+# optional per-launch timing (bench.py): (kernel family, algorithmic FLOPs, start event, end event)
+PROFILE_ON = False
+PROFILE = []
+
+
+def _variant(Cin_split, Cout, esize):
+    ck = 64 // esize
+    ok = all(c % ck == 0 for c in Cin_split if c) and Cout % 64 == 0
+    if ok:
+        return "mfma"
+    return "stem" if sum(Cin_split) <= 4 else "generic"
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE_ON:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE_ON:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+
 
 # ----------------------------------------------------------------------------- helpers
 def _require_gpu(t: torch.Tensor, what: str = "tensor"):
@@ -122,8 +151,10 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
     if want_stats:
         nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, C0 + C1, Cout, dt)
         stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=x0.device)
-    LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
-             w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt, _stream())
+    name = "conv3x3_fwd_" + _variant((C0, C1), Cout, x0.element_size())
+    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1)):
+        LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
+                 w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt, _stream())
     return y, stats, nslab
 
 
@@ -134,8 +165,54 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
     dt = _dt(dy)
     nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, C0 + C1, Cout, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
-             0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
+    name = "conv3x3_wgrad_" + ("mfma" if (C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0) else
+                                ("stem" if C0 + C1 <= 4 else "generic"))
+    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1)):
+        LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
+                 0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
+
+
+def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.dtype, iters: int = 20):
+    """Time the conv kernels of one DoubleConv(Cin -> Cout -> Cout) in isolation (HIP events on the launch
+    stream, `iters` back-to-back launches each).  Returns TFLOP/s per kernel; used by bench.py for the layer
+    the north-star's MFMA target is quoted on (the 256-channel DoubleConv)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, dtype)
+    h = torch.randn(B, H, W, Cout, generator=g).to(dev, dtype)
+    w1 = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    w2 = (torch.randn(Cout, Cout, 3, 3, generator=g) / (3 * Cout ** 0.5)).to(dev)
+    w1f, w1d = pack_w3x3(w1, dtype, True)
+    w2f, w2d = pack_w3x3(w2, dtype, True)
+    dw = torch.empty(Cout * 9 * Cout, dtype=torch.float32, device=dev)
+
+    def timeit(fn, flops):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        return {"ms": round(ms, 4), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+
+    f1 = 2.0 * B * H * W * Cout * 9 * Cin
+    f2 = 2.0 * B * H * W * Cout * 9 * Cout
+    out = {
+        "shape": f"B{B} {H}x{W} {Cin}->{Cout}->{Cout} {str(dtype)[6:]}",
+        "fwd_conv1": timeit(lambda: conv3x3_fwd(x, None, w1f, Cout, True), f1),
+        "fwd_conv2": timeit(lambda: conv3x3_fwd(h, None, w2f, Cout, True), f2),
+        "dgrad_conv2": timeit(lambda: conv3x3_fwd(h, None, w2d, Cout, False), f2),
+        "dgrad_conv1": timeit(lambda: conv3x3_fwd(h, None, w1d, Cin, False), f1),
+        "wgrad_conv2": timeit(lambda: conv3x3_wgrad(h, h, None, dw), f2),
+        "wgrad_conv1": timeit(lambda: conv3x3_wgrad(h, x, None, dw[:Cout * 9 * Cin]), f1),
+    }
+    tot_f = 3 * f2 + 3 * f1
+    tot_ms = sum(v["ms"] for k, v in out.items() if isinstance(v, dict))
+    out["all_six"] = {"ms": round(tot_ms, 4), "tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1)}
+    return out
 
 
 # ----------------------------------------------------------------------------- conv + BN + ReLU
