@@ -167,7 +167,7 @@ extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, cons
 extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
     (void)C;
     int64_t n = (npix + 511) / 512;
-    if (n > 2048) n = 2048;
+    if (n > 512) n = 512;
     if (n < 1) n = 1;
     return (int)n;
 }
@@ -254,14 +254,14 @@ extern "C" int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, in
     return UH_OK;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double red[2][4][64];   // double: sum(dz) cancels heavily behind a BatchNorm
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][16][64];   // double: sum(dz) cancels heavily behind a BatchNorm
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int s = sl; s < nblk; s += 4) {
+        for (int s = sl; s < nblk; s += 16) {
             a += (double)partials[((int64_t)s * 2 + 0) * C + c];
             b += (double)partials[((int64_t)s * 2 + 1) * C + c];
         }
@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     red[1][sl][cl] = b;
     __syncthreads();
     if (sl == 0 && c < C) {
-        dbeta[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
-        dgamma[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+        double x = 0.0, y = 0.0;
+        for (int k = 0; k < 16; ++k) { x += red[0][k][cl]; y += red[1][k][cl]; }
+        dbeta[c] = (float)x;
+        dgamma[c] = (float)y;
     }
 }
 
@@ -310,7 +312,7 @@ extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int
                "uh_bn_relu_bwd_apply: null pointer");
     UH_REQUIRE(npix > 0 && C > 0 && nblk > 0 && lddz >= C && ldy >= C && lddy >= C, "uh_bn_relu_bwd_apply: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partials, nblk, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
     UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     float inv_n = (float)(1.0 / (double)npix);
     UH_DISPATCH_DT(dt, T, {

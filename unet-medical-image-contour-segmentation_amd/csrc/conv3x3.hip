@@ -164,10 +164,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
     stage_store(0);
     __syncthreads();
 
+    // Filter fragments are software-pipelined one tap ahead in registers (global -> VGPR, L2 resident): the
+    // loads of tap t+1 are issued before the 8*NB MFMAs of tap t, so their latency hides under ~0.5k MFMA cycles.
+    u32x4 wcur[NB], wnxt[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) wcur[n] = *reinterpret_cast<const u32x4*>(wl + n * wnb_stride);
+
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) stage_load(c + 1);
         const unsigned char* buf = lds + (c & 1) * HALO_BYTES;
         const T* wc = wl + c * CK;
+        const T* wc_next = wl + ((c + 1 < nchunk) ? (c + 1) : c) * CK;      // clamped: the last prefetch is unused
         const unsigned char* xrow = buf + ((wm * 8) * HALO_W + lx) * PSTR + kg * 16;
 #pragma unroll 1
         for (int s = 0; s < 3; ++s) {
@@ -177,20 +184,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
                 xf[k] = *reinterpret_cast<const u32x4*>(xrow + (k * HALO_W + s) * PSTR);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const int tap = r * 3 + s;
-                u32x4 wf[NB];
+                // next tap in issue order: (s, r+1) -> (s+1, 0) -> next chunk (0, 0)
+                const T* wn = (r < 2) ? (wc + ((r + 1) * 3 + s) * Cin)
+                                      : ((s < 2) ? (wc + (s + 1) * Cin) : wc_next);
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    wf[n] = *reinterpret_cast<const u32x4*>(wc + n * wnb_stride + tap * Cin);
+                    wnxt[n] = *reinterpret_cast<const u32x4*>(wn + n * wnb_stride);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this tap's MFMAs
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         if constexpr (ES == 2) {
                             acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                                __builtin_bit_cast(bf16x8, wcur[n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
                         } else {
-                            f32x4 a = __builtin_bit_cast(f32x4, wf[n]);
+                            f32x4 a = __builtin_bit_cast(f32x4, wcur[n]);
                             f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
@@ -198,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
                         }
                     }
                 }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) wcur[n] = wnxt[n];
             }
         }
         if (c + 1 < nchunk) stage_store((c + 1) & 1);
@@ -284,6 +295,208 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
             stats[((int64_t)blockIdx.x * 2 + 0) * Cout + co_blk + tid] = red[2 * BN + tid];
             stats[((int64_t)blockIdx.x * 2 + 1) * Cout + co_blk + tid] = red[tid] + red[BN + tid];
         }
+        if (blockIdx.y == 0 && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
+    }
+}
+
+// =====================================================================================
+// forward, MFMA implicit GEMM, v2: the hot variant.
+//   * wave w of the workgroup owns ALL 256 pixels of the tile x its own NBW*16 output channels, so filter
+//     fragments (global -> VGPR, 16 B per lane) are loaded by exactly one wave each: no redundant L2 traffic
+//     (v1's 2x2 wave grid re-read every filter element twice and ran into the L2 bandwidth roof);
+//   * the 18x18 halo tile goes global -> LDS by DMA (buffer_load ... lds, zero VGPRs, out-of-image pixels read
+//     as zeros through the descriptor's range check), double buffered, 64-byte pixel pitch with an XOR swizzle
+//     of the four 16-byte parts applied on the SOURCE address;
+//   * a halo row fragment is read from LDS once per column shift and used by the three row taps (rolling
+//     window of 3 rows); the filter fragments of the next column shift are prefetched under the current one;
+//   * BatchNorm (mean, M2) per tile and channel come straight from the accumulator registers + 4 shuffles.
+// =====================================================================================
+constexpr int HALO2_BYTES = HALO_PIX * 64;   // 20736
+constexpr unsigned OOB_OFFSET = 0xF0000000u;
+
+__device__ __forceinline__ int halo_swz(int q) { return (4 - ((q >> 2) & 3)) & 3; }
+
+template <typename T, int NBW>
+__global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
+    const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
+    const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
+    int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes) {
+    constexpr int ES = sizeof(T);
+    constexpr int CK = 64 / ES;
+    constexpr int VEC = 16 / ES;
+    constexpr int BN = NBW * 64;
+    constexpr int NPIECE = HALO_PIX * 4;     // 1296
+    constexpr int NLOAD = 6;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lx = lane & 15, kg = lane >> 4;
+
+    int t = blockIdx.x;
+    const int txt = t % tilesX; t /= tilesX;
+    const int tyt = t % tilesY;
+    const int b = t / tilesY;
+    const int y0 = tyt * TILE, x0p = txt * TILE;
+    const int co_blk = blockIdx.y * BN;
+    const int co_w = co_blk + wave * (NBW * 16);
+    const int Cin = C0 + C1;
+    const int nchunk = Cin / CK;
+
+    // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q)
+    int pix_idx[NLOAD];
+    int src_part[NLOAD];
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+        int p = tid + k * 256;
+        int q = p >> 2;
+        int hy = q / HALO_W, hx = q - hy * HALO_W;
+        int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+        bool ok = (p < NPIECE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        pix_idx[k] = ok ? ((b * H + gy) * W + gx) : -1;
+        src_part[k] = ((p & 3) ^ halo_swz(q)) * 16;
+    }
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, (int)x0_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 ? x1 : x0), 0, (int)(x1 ? x1_bytes : x0_bytes), 0x00020000);
+
+    auto dma_chunk = [&](int c, int bufi) {
+        const int cc = c * CK;
+        const bool first = cc < C0;
+        const int ld = first ? ld0 : ld1;
+        const int soff = (first ? cc : cc - C0) * ES;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        unsigned char* dst = lds + bufi * HALO2_BYTES + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            unsigned voff = pix_idx[k] >= 0 ? (unsigned)(pix_idx[k] * ld * ES + src_part[k]) : OOB_OFFSET;
+            if (k < NLOAD - 1 || tid + k * 256 < NPIECE) {
+                if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[16][NBW];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* wl = w + (int64_t)(co_w + lx) * 9 * Cin + kg * VEC;
+    const int64_t wnb_stride = (int64_t)16 * 9 * Cin;
+
+    dma_chunk(0, 0);
+    u32x4 wc[3][NBW], wn[3][NBW];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) wc[r][n] = *reinterpret_cast<const u32x4*>(wl + n * wnb_stride + (r * 3) * Cin);
+    __syncthreads();     // drains the DMA (vmcnt(0)) before anyone reads buffer 0
+
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) dma_chunk(c + 1, (c + 1) & 1);
+        const unsigned char* buf = lds + (c & 1) * HALO2_BYTES;
+        const T* wcp = wl + c * CK;
+        const T* wcp_next = wl + ((c + 1 < nchunk) ? (c + 1) : c) * CK;
+#pragma unroll 1
+        for (int s = 0; s < 3; ++s) {
+            // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
+            const T* wsrc = (s < 2) ? (wcp + (s + 1) * Cin) : wcp_next;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n)
+                    wn[r][n] = *reinterpret_cast<const u32x4*>(wsrc + n * wnb_stride + (r * 3) * Cin);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 xf[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                const int q = k * HALO_W + lx + s;
+                xf[k] = *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
+                if (k >= 2) {
+                    const int i = k - 2;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) {
+                            if constexpr (ES == 2) {
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                            } else {
+                                f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
+                                f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+#pragma unroll
+                                for (int qq = 0; qq < 4; ++qq)
+                                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) wc[r][n] = wn[r][n];
+        }
+        __syncthreads();     // next chunk's DMA has landed (vmcnt(0) + barrier); this chunk's buffer is free again
+    }
+
+    // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + n*16 + kg*4 + j]; this wave holds the
+    // whole tile for its channels, so the tile statistics need only 4 shuffles per value.
+    const int gx = x0p + lx;
+    const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+    const float inv_cnt = 1.f / (float)(vy * vx);
+    float ssum[NBW][4];
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ssum[n][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int gy = y0 + i;
+        const bool ok = (gy < H) && (gx < W);
+        T* yp = y + (int64_t)((b * H + gy) * W + gx) * ldy + co_w + kg * 4;
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
+                ssum[n][j] += ok ? acc[i][n][j] : 0.f;
+            }
+            if (ok) {
+                if constexpr (ES == 2) {
+                    bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
+                    *reinterpret_cast<bf16x4*>(yp + n * 16) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(yp + n * 16) = acc[i][n];
+                }
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) ssum[n][j] += __shfl_xor(ssum[n][j], o, 64);
+                const float mu = ssum[n][j] * inv_cnt;
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool ok = (y0 + i < H) && (gx < W);
+                    float d = acc[i][n][j] - mu;
+                    a += ok ? d * d : 0.f;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (lx == 0) {
+                    const int ch = co_w + n * 16 + kg * 4 + j;
+                    stats[((int64_t)blockIdx.x * 2 + 0) * Cout + ch] = mu;
+                    stats[((int64_t)blockIdx.x * 2 + 1) * Cout + ch] = a;
+                }
+            }
         if (blockIdx.y == 0 && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
     }
 }
@@ -448,6 +661,18 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                          (C1 == 0 || uh_aligned16(x1)) && uh_aligned16(w) && uh_aligned16(y) &&
                          ((ld0 * ES) % 16 == 0) && (C1 == 0 || (ld1 * ES) % 16 == 0) && ((ldy * ES) % 16 == 0);
     if (mfma_ok) {
+        const int64_t b0 = (int64_t)B * H * W * ld0 * ES, b1 = C1 ? (int64_t)B * H * W * ld1 * ES : 0;
+        if (b0 < (1ll << 31) - 4096 && b1 < (1ll << 31) - 4096) {
+            // 128-channel slabs halve the halo re-reads, but small feature maps need the extra workgroups
+            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512)
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(ntile, Cout / 128), dim3(256), 0, st, x0, C0, ld0, x1,
+                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
+            else
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(ntile, Cout / 64), dim3(256), 0, st, x0, C0, ld0, x1,
+                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
+            UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
+            return UH_OK;
+        }
         if (Cout % 128 == 0) {
             hipLaunchKernelGGL((conv3x3_fwd_mfma<T, 4>), dim3(ntile, Cout / 128), dim3(256), 0, st, x0, C0, ld0, x1, C1,
                                ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY);
@@ -663,7 +888,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
         }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nsplit) {
+// out[i] = sum_k slabs[k][i]; block = 64 float4 columns x 4 split lanes, 4 independent loads in flight per lane
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
+                                                          int nsplit) {
+    __shared__ f32x4 red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i4 = (int64_t)blockIdx.x * 64 + cl;
+    const int64_t n4 = n >> 2;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (i4 < n4) {
+        const f32x4* base = reinterpret_cast<const f32x4*>(slabs) + i4;
+        int k = sl;
+        for (; k + 12 < nsplit; k += 16) {
+            a0 += base[(int64_t)k * n4];
+            a1 += base[(int64_t)(k + 4) * n4];
+            a2 += base[(int64_t)(k + 8) * n4];
+            a3 += base[(int64_t)(k + 12) * n4];
+        }
+        for (; k < nsplit; k += 4) a0 += base[(int64_t)k * n4];
+    }
+    red[sl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && i4 < n4) reinterpret_cast<f32x4*>(out)[i4] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__global__ void slab_reduce_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nsplit) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
@@ -791,14 +1040,14 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned
         p.tilesX = (W + TILE - 1) / TILE; p.tilesY = (H + TH - 1) / TH;
         p.ntile = B * p.tilesX * p.tilesY;
         int ctiles = (Cin / 64) * (Cout / 64);
-        int want = (1024 + ctiles - 1) / ctiles;      // ~4 workgroups per CU in flight
+        int want = (512 + ctiles - 1) / ctiles;       // ~2 workgroups per CU in flight (LDS allows 2)
         p.nsplit = want < 1 ? 1 : (want > p.ntile ? p.ntile : want);
     } else if (Cin <= 4) {
         p.kind = 1;
         p.tilesX = (W + TILE - 1) / TILE; p.tilesY = (H + TILE - 1) / TILE;
         p.ntile = B * p.tilesX * p.tilesY;
         int cg = (Cout + 63) / 64;
-        int want = (1024 + cg - 1) / cg;
+        int want = (512 + cg - 1) / cg;
         p.nsplit = want > p.ntile ? p.ntile : want;
     } else {
         p.kind = 2; p.nsplit = 0; p.tilesX = p.tilesY = p.ntile = 0;
@@ -843,9 +1092,13 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
                            ld0, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
         UH_CHECK_LAUNCH("conv3x3_wgrad_stem");
     }
-    int64_t n = (int64_t)Cout * 9 * Cin;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)slabs, dw, n,
-                       p.nsplit);
+    int64_t n = (int64_t)Cout * 9 * Cin;      // multiple of 4 on every slab path (Cout % 64 == 0 or 9*... stem: Cout*9*Cin)
+    if (n % 4 != 0 || !uh_aligned16(dw) || !uh_aligned16(slabs))
+        hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const float*)slabs, dw, n, p.nsplit);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, st, (const float*)slabs,
+                           dw, n, p.nsplit);
     UH_CHECK_LAUNCH("slab_reduce_kernel");
     return UH_OK;
 }

@@ -228,68 +228,85 @@ __global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restr
     }
 }
 
-// thread = (pixel lane, channel); block partials [nblk][ncls][Cin + 1] (last column = dbias)
-template <typename T>
+// thread = (pixel lane, channel group of V); block partials [nblk][ncls][Cin + 1] (last column = dbias)
+template <typename T, int V, int NC>
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ dl, const T* __restrict__ x, int ldx,
-                                                            float* __restrict__ partials, int64_t npix, int Cin, int ncls) {
-    extern __shared__ float red[];   // [PL][ncls][CB+1]
-    const int CB = Cin < 256 ? Cin : 256;
-    const int PL = 256 / CB;
-    const int cl = threadIdx.x % CB, pl = threadIdx.x / CB;
+                                                            float* __restrict__ partials, int64_t npix, int Cin) {
+    extern __shared__ float red[];   // [PL][NC][GB*V + 1]
+    const int G = Cin / V;
+    const int GB = G < 256 ? G : 256;
+    const int PL = 256 / GB;
+    const int RW = GB * V + 1;
+    const int gl = threadIdx.x % GB, pl = threadIdx.x / GB;
     const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
-    for (int cb = 0; cb < Cin; cb += CB) {
-        const int c = cb + cl;
-        float acc[MAXCLS], bs[MAXCLS];
+    for (int gb = 0; gb < G; gb += GB) {
+        const int c = (gb + gl) * V;
+        float acc[NC][V], bs[NC];
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) { acc[k] = 0.f; bs[k] = 0.f; }
-        if (pl < PL && c < Cin)
+        for (int k = 0; k < NC; ++k) {
+            bs[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
+        }
+        const bool act = pl < PL && gb + gl < G;
+        if (act)
             for (int64_t p = p0 + pl; p < p1; p += PL) {
-                float xv = uh_to_f32(x[p * ldx + c]);
+                float xv[V];
+                uh_load<T, V>(x + p * ldx + c, xv);
 #pragma unroll
-                for (int k = 0; k < MAXCLS; ++k)
-                    if (k < ncls) {
-                        float g = dl[p * ncls + k];
-                        acc[k] = fmaf(g, xv, acc[k]);
-                        bs[k] += g;
-                    }
+                for (int k = 0; k < NC; ++k) {
+                    float g = dl[p * NC + k];
+                    bs[k] += g;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[k][i] = fmaf(g, xv[i], acc[k][i]);
+                }
             }
         __syncthreads();
-        if (pl < PL) {
+        if (act) {
 #pragma unroll
-            for (int k = 0; k < MAXCLS; ++k)
-                if (k < ncls) {
-                    red[(pl * ncls + k) * (CB + 1) + cl] = acc[k];
-                    if (cl == 0) red[(pl * ncls + k) * (CB + 1) + CB] = bs[k];
-                }
+            for (int k = 0; k < NC; ++k) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) red[(pl * NC + k) * RW + gl * V + i] = acc[k][i];
+                if (gl == 0) red[(pl * NC + k) * RW + GB * V] = bs[k];
+            }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < ncls * (CB + 1); k += 256) {
-            int cls = k / (CB + 1), cc = k - cls * (CB + 1);
+        for (int k = threadIdx.x; k < NC * RW; k += 256) {
+            int cls = k / RW, cc = k - cls * RW;
             float v = 0.f;
-            for (int q = 0; q < PL; ++q) v += red[(q * ncls + cls) * (CB + 1) + cc];
-            float* row = partials + ((int64_t)blockIdx.x * ncls + cls) * (Cin + 1);
-            if (cc < CB) { if (cb + cc < Cin) row[cb + cc] = v; }
-            else if (cb == 0) row[Cin] = v;
+            for (int q = 0; q < PL; ++q) v += red[(q * NC + cls) * RW + cc];
+            float* row = partials + ((int64_t)blockIdx.x * NC + cls) * (Cin + 1);
+            if (cc < GB * V) { if (gb * V + cc < Cin) row[gb * V + cc] = v; }
+            else if (gb == 0) row[Cin] = v;
         }
     }
 }
 
-__global__ void conv1x1_wgrad_reduce_kernel(const float* __restrict__ partials, int nblk, int Cin, int ncls,
-                                            float* __restrict__ dw, float* __restrict__ dbias) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = ncls * (Cin + 1);
-    if (idx >= n) return;
+// one block per output element: tree reduction over the partial rows in double
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ partials, int nblk, int Cin, int ncls,
+                                                                   float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ double red[256];
+    const int idx = blockIdx.x;
+    const int n = ncls * (Cin + 1);
     double v = 0.0;
-    for (int b = 0; b < nblk; ++b) v += (double)partials[(int64_t)b * n + idx];
-    int cls = idx / (Cin + 1), c = idx - cls * (Cin + 1);
-    if (c < Cin) dw[cls * Cin + c] = (float)v;
-    else dbias[cls] = (float)v;
+    for (int b = threadIdx.x; b < nblk; b += 256) v += (double)partials[(int64_t)b * n + idx];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int cls = idx / (Cin + 1), c = idx - cls * (Cin + 1);
+        if (c < Cin) dw[cls * Cin + c] = (float)red[0];
+        else dbias[cls] = (float)red[0];
+    }
 }
 
 static int c11_nblk(int64_t npix) {
-    int64_t n = (npix + 1023) / 1024;
-    if (n > 1024) n = 1024;
+    int64_t n = (npix + 4095) / 4096;
+    if (n > 512) n = 512;
     if (n < 1) n = 1;
     return (int)n;
 }
@@ -349,16 +366,28 @@ extern "C" int uh_conv1x1_wgrad(const float* dlogits, const void* x, int ldx, fl
         return UH_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int CB = Cin < 256 ? Cin : 256, PL = 256 / CB;
-    size_t sm = (size_t)PL * ncls * (CB + 1) * sizeof(float);
+#define UH_C11_LAUNCH(T, V, NC)                                                                                      \
+    do {                                                                                                             \
+        int G = Cin / (V), GB = G < 256 ? G : 256, PL = 256 / GB;                                                    \
+        size_t sm = (size_t)PL * (NC) * (GB * (V) + 1) * sizeof(float);                                              \
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, V, NC>), dim3(nblk), dim3(256), sm, st, dlogits, (const T*)x, ldx, \
+                           (float*)ws, npix, Cin);                                                                   \
+    } while (0)
+#define UH_C11_NC(T, V)                                                                    \
+    switch (ncls) {                                                                        \
+        case 1: UH_C11_LAUNCH(T, V, 1); break; case 2: UH_C11_LAUNCH(T, V, 2); break;      \
+        case 3: UH_C11_LAUNCH(T, V, 3); break; case 4: UH_C11_LAUNCH(T, V, 4); break;      \
+        case 5: UH_C11_LAUNCH(T, V, 5); break; case 6: UH_C11_LAUNCH(T, V, 6); break;      \
+        case 7: UH_C11_LAUNCH(T, V, 7); break; default: UH_C11_LAUNCH(T, V, 8); break;     \
+    }
     UH_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel<T>, dim3(nblk), dim3(256), sm, st, dlogits, (const T*)x, ldx, (float*)ws,
-                           npix, Cin, ncls);
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (uh_vec_ok<T>(x, ldx, Cin) && ncls <= 4) { UH_C11_NC(T, VEC) }
+        else { UH_C11_NC(T, 1) }
     });
     UH_CHECK_LAUNCH("conv1x1_wgrad_kernel");
     int n = ncls * (Cin + 1);
-    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, nblk, Cin,
-                       ncls, dw, dbias);
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(n), dim3(256), 0, st, (const float*)ws, nblk, Cin, ncls, dw, dbias);
     UH_CHECK_LAUNCH("conv1x1_wgrad_reduce_kernel");
     return UH_OK;
 }

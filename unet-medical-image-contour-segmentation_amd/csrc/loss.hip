@@ -39,12 +39,28 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[K], float* row) {
     if (threadIdx.x < K) row[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void loss_finish_kernel(const float* __restrict__ partials, int nblk, int K, float* __restrict__ out) {
-    int k = threadIdx.x;
-    if (k >= K) return;
+// one block of 256 threads: column sums of partials[nblk][LOSS_ROW] in double (tree reduction)
+__device__ __forceinline__ double column_sum_256(const float* __restrict__ partials, int nblk, int k, double* red) {
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(int64_t)b * LOSS_ROW + k];
-    out[k] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partials[(int64_t)b * LOSS_ROW + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partials, int nblk, int K,
+                                                          float* __restrict__ out) {
+    __shared__ double red[256];
+    for (int k = 0; k < K; ++k) {
+        double s = column_sum_256(partials, nblk, k, red);
+        if (threadIdx.x == 0) out[k] = (float)s;
+    }
 }
 
 __device__ __forceinline__ float bin_target(const int64_t* mask, int mask_div, const float* tf, int64_t i) {
@@ -79,7 +95,7 @@ extern "C" int uh_bce_dice_sums(const float* logits, const int64_t* mask, int ma
     int nblk = loss_nblk(n);
     hipLaunchKernelGGL(bce_dice_sums_kernel, dim3(nblk), dim3(256), 0, st, logits, mask, mask_div, target_f, n, (float*)ws);
     UH_CHECK_LAUNCH("bce_dice_sums_kernel");
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, nblk, 4, sums);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nblk, 4, sums);
     UH_CHECK_LAUNCH("loss_finish_kernel");
     return UH_OK;
 }
@@ -217,7 +233,7 @@ extern "C" int uh_ce_dice_sums(const float* logits, const int64_t* mask, int64_t
     int nblk = loss_nblk(npix);
     UH_NC_SWITCH(ncls, hipLaunchKernelGGL(ce_dice_sums_kernel<NC>, dim3(nblk), dim3(256), 0, st, logits, mask, npix, (float*)ws););
     UH_CHECK_LAUNCH("ce_dice_sums_kernel");
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, nblk, 1 + 3 * ncls, sums);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nblk, 1 + 3 * ncls, sums);
     UH_CHECK_LAUNCH("loss_finish_kernel");
     return UH_OK;
 }
@@ -394,12 +410,12 @@ __device__ float boundary_region_loss(double inter, double psum, double tsum, do
     return (1.f - iou) + 0.5f * (float)(bce / N);
 }
 
-__global__ void boundary_finish_kernel(const float* __restrict__ partials, int nblk, int B, BRegion g, float edge_weight,
-                                       float smooth, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void boundary_finish_kernel(const float* __restrict__ partials, int nblk, int B, BRegion g,
+                                                              float edge_weight, float smooth, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s[6];
+    for (int k = 0; k < 6; ++k) s[k] = column_sum_256(partials, nblk, k, red);
     if (threadIdx.x != 0) return;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < nblk; ++b)
-        for (int k = 0; k < 6; ++k) s[k] += (double)partials[(int64_t)b * LOSS_ROW + k];
     double n_int = 0.0, n_edge = 0.0;
     const double tot = (double)g.H * g.W;
     if (g.ew == 0) { n_int = tot; n_edge = 0.0; }
@@ -431,7 +447,7 @@ extern "C" int uh_boundary_loss(const float* pred, int64_t pstride, int64_t bstr
     hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, B, g,
                        (const float*)mmbuf, nmm, partials);
     UH_CHECK_LAUNCH("boundary_count_kernel");
-    hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)partials, nblk, B, g, edge_weight,
+    hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, B, g, edge_weight,
                        smooth, out);
     UH_CHECK_LAUNCH("boundary_finish_kernel");
     return UH_OK;
