@@ -727,7 +727,7 @@ extern "C" int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, i
 // dy row hy - r.
 // =====================================================================================
 template <typename T> struct WgradCfg;
-template <> struct WgradCfg<bf16_t> { static constexpr int TH = 16; };   // pixel-tile rows
+template <> struct WgradCfg<bf16_t> { static constexpr int TH = 8; };    // pixel-tile rows
 template <> struct WgradCfg<float> { static constexpr int TH = 8; };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -912,6 +912,138 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     if (sl == 0 && i4 < n4) reinterpret_cast<f32x4*>(out)[i4] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// =====================================================================================
+// backward-weights v2 (bf16): same MFMA mapping as conv3x3_wgrad_mfma, but 8-row pixel tiles whose two
+// [pixel][64 channel] LDS images (x halo 10x18, dy 8x16) are filled by LDS-DMA (buffer_load ... lds, zero
+// padding through the descriptor range check) and double buffered: the DMA of tile t+1 is issued right after
+// the barrier that retires tile t-1 and lands under the 72 MFMAs per wave of tile t.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
+    const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
+    int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
+    unsigned dy_bytes, unsigned x_bytes) {
+    static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
+    constexpr int TH = 8;
+    constexpr int PB = 128;                     // bytes per pixel: 64 bf16 channels
+    constexpr int XPIX = (TH + 2) * HALO_W;     // 180
+    constexpr int DPIX = TH * TILE;             // 128
+    constexpr int XUNITS = XPIX * 8, DUNITS = DPIX * 8;      // 16-byte units
+    constexpr int XBYTES = XPIX * PB, STAGE = (XPIX + DPIX) * PB;   // 23040, 39424
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int Cin = C0 + C1;
+    const int nci = Cin / 64;
+    const int cot = blockIdx.y / nci, cit = blockIdx.y - cot * nci;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const T* xsrc; int ldx;
+    if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; }
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc, 0, (int)x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)dy_bytes, 0x00020000);
+
+    const int ntile = B * tilesX * tilesY;
+    const int split = blockIdx.x;
+    const int t_begin = (int)(((int64_t)ntile * split) / nsplit);
+    const int t_end = (int)(((int64_t)ntile * (split + 1)) / nsplit);
+
+    auto issue = [&](int tile, int bufi) {
+        int t = tile;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TH, x0p = txt * TILE;
+        unsigned char* xb = lds + bufi * STAGE + wave * 1024;
+        unsigned char* db = xb + XBYTES;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int p = tid + k * 256;
+            const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+            const int hy = q / HALO_W, hx = q - hy * HALO_W;
+            const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            unsigned voff = ok ? (unsigned)(((b * H + gy) * W + gx) * ldx * 2 + u * 16) : OOB_OFFSET;
+            if (k < 5 || p < XUNITS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = tid + k * 256;
+            const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+            const int gy = y0 + (q >> 4), gx = x0p + (q & 15);
+            const bool ok = gy < H && gx < W;
+            unsigned voff = ok ? (unsigned)(((b * H + gy) * W + gx) * lddy * 2 + u * 16) : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(db + k * 4096), 16, voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    auto lds_addr = [&](int q, int byte) -> int { return q * PB + (byte ^ (((q >> 1) & 1) << 6)); };
+    const int l16 = lane & 15;
+    const int grp = (lane >> 4) & 1;
+    const int kh = lane >> 5;
+    const int rq = l16 >> 2, cp = l16 & 3;
+    const int a_cbyte = (wr * 32 + grp * 16 + cp * 4) * 2;
+    const int b_cbyte = (wc * 32 + grp * 16 + cp * 4) * 2;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+    if (t_begin < t_end) issue(t_begin, 0);
+    __syncthreads();
+    int bufi = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        const unsigned char* xs = lds + bufi * STAGE;
+        const unsigned char* ds = xs + XBYTES;
+        bf16x8 dfrag[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dfrag[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int hy = 0; hy < TH + 2; ++hy) {
+            dfrag[2] = dfrag[1];
+            dfrag[1] = dfrag[0];
+            if (hy < TH) {
+                int qa = hy * TILE + kh * 8 + rq;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ds + lds_addr(qa, a_cbyte)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ds + lds_addr(qa + 4, a_cbyte)));
+                s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                dfrag[0] = __builtin_bit_cast(bf16x8, both);
+            } else {
+                dfrag[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                int qb = hy * HALO_W + s + kh * 8 + rq;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xs + lds_addr(qb, b_cbyte)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xs + lds_addr(qb + 4, b_cbyte)));
+                s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8 xf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (hy - r >= 0 && hy - r < TH)
+                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag[r], xf, acc[r * 3 + s], 0, 0, 0);
+            }
+        }
+        __syncthreads();    // drains the DMA of tile+1 (vmcnt(0)) and frees this buffer
+    }
+
+    float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
+    const int ci = ci0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int co = co0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            slab[((int64_t)co * 9 + tap) * Cin + ci] = acc[tap][reg];
+        }
+}
+
 __global__ void slab_reduce_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nsplit) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1084,9 +1216,24 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     }
     float* slabs = (float*)ws;
     if (p.kind == 0) {
-        hipLaunchKernelGGL(conv3x3_wgrad_mfma<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy, lddy, x0,
-                           C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
-        UH_CHECK_LAUNCH("conv3x3_wgrad_mfma");
+        const int64_t npx = (int64_t)B * H * W;
+        const int64_t ldmax = ld0 > ld1 ? ld0 : ld1;
+        bool dma = false;
+        if constexpr (ES == 2) dma = npx * ldmax * 2 < (1ll << 31) - 4096 && npx * lddy * 2 < (1ll << 31) - 4096;
+        if constexpr (ES == 2) {
+            if (dma) {
+                // byte extents of the (sliced) source views as seen from their base pointers
+                unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
+                hipLaunchKernelGGL(conv3x3_wgrad_mfma_v2<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
+                                   lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb);
+                UH_CHECK_LAUNCH("conv3x3_wgrad_mfma_v2");
+            }
+        }
+        if (!dma) {
+            hipLaunchKernelGGL(conv3x3_wgrad_mfma<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy, lddy,
+                               x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+            UH_CHECK_LAUNCH("conv3x3_wgrad_mfma");
+        }
     } else {
         hipLaunchKernelGGL(conv3x3_wgrad_stem<T>, dim3(p.nsplit, (Cout + 63) / 64), dim3(256), 0, st, dy, lddy, x0, Cin,
                            ld0, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
