@@ -1,5 +1,5 @@
 import sys, torch, json
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import unet_amd
 from unet_amd import ops
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] != 'f32') else torch.float32

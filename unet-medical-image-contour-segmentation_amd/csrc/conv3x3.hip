@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
 constexpr int HALO2_BYTES = HALO_PIX * 64;   // 20736
 constexpr unsigned OOB_OFFSET = 0xF0000000u;
 
-__device__ __forceinline__ int halo_swz(int q) { return (4 - ((q >> 2) & 3)) & 3; }
+// XOR applied to the 16-byte part index of halo pixel q: with part' = part ^ (2 * ((q >> 2) & 1)) the 16 lanes of
+// every ds_read_b128 lane group (8 lanes of part k, 8 of part k^1, 16 consecutive pixels at ANY start) hit 16
+// distinct 16-byte slots of the 256-byte bank row -> conflict-free fragment reads for all nine taps.
+__device__ __forceinline__ int halo_swz(int q) { return ((q >> 2) & 1) << 1; }
 
 template <typename T, int NBW>
 __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
@@ -410,29 +413,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
                 for (int n = 0; n < NBW; ++n)
                     wn[r][n] = *reinterpret_cast<const u32x4*>(wsrc + n * wnb_stride + (r * 3) * Cin);
             __builtin_amdgcn_sched_barrier(0);
+            // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
             u32x4 xf[18];
-#pragma unroll
-            for (int k = 0; k < 18; ++k) {
+            auto rd = [&](int k) {
                 const int q = k * HALO_W + lx + s;
-                xf[k] = *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
-                if (k >= 2) {
-                    const int i = k - 2;
+                return *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
+            };
+            xf[0] = rd(0);
+            xf[1] = rd(1);
+            xf[2] = rd(2);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+            for (int k = 2; k < 18; ++k) {
+                if (k + 1 < 18) xf[k + 1] = rd(k + 1);
+                __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
+                const int i = k - 2;
 #pragma unroll
-                        for (int n = 0; n < NBW; ++n) {
-                            if constexpr (ES == 2) {
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
-                            } else {
-                                f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
-                                f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                                for (int qq = 0; qq < 4; ++qq)
-                                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
-                            }
+                    for (int n = 0; n < NBW; ++n) {
+                        if constexpr (ES == 2) {
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                        } else {
+                            f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
+                            f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq)
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
                         }
-                }
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -1001,34 +1010,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
-        bf16x8 dfrag[3];
+        // fragments of halo row hy+1 are fetched (transposed LDS reads) while row hy is multiplied
+        auto tr_pair = [&](const unsigned char* base, int q, int cbyte) -> bf16x8 {
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lds_addr(q, cbyte)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lds_addr(q + 4, cbyte)));
+            s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, both);
+        };
+        const bf16x8 zero8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 dfrag[3] = {zero8, zero8, zero8};
+        bf16x8 dcur = tr_pair(ds, kh * 8 + rq, a_cbyte), dnxt = zero8;
+        bf16x8 xcur[3], xnxt[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dfrag[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < 3; ++s) xcur[s] = tr_pair(xs, s + kh * 8 + rq, b_cbyte);
 #pragma unroll 1
         for (int hy = 0; hy < TH + 2; ++hy) {
+            if (hy + 1 < TH + 2) {
+                dnxt = (hy + 1 < TH) ? tr_pair(ds, (hy + 1) * TILE + kh * 8 + rq, a_cbyte) : zero8;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) xnxt[s] = tr_pair(xs, (hy + 1) * HALO_W + s + kh * 8 + rq, b_cbyte);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             dfrag[2] = dfrag[1];
             dfrag[1] = dfrag[0];
-            if (hy < TH) {
-                int qa = hy * TILE + kh * 8 + rq;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ds + lds_addr(qa, a_cbyte)));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ds + lds_addr(qa + 4, a_cbyte)));
-                s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                dfrag[0] = __builtin_bit_cast(bf16x8, both);
-            } else {
-                dfrag[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            dfrag[0] = dcur;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                int qb = hy * HALO_W + s + kh * 8 + rq;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xs + lds_addr(qb, b_cbyte)));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xs + lds_addr(qb + 4, b_cbyte)));
-                s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bf16x8 xf = __builtin_bit_cast(bf16x8, both);
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
                     if (hy - r >= 0 && hy - r < TH)
-                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag[r], xf, acc[r * 3 + s], 0, 0, 0);
-            }
+                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag[r], xcur[s], acc[r * 3 + s], 0, 0, 0);
+            dcur = dnxt;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xcur[s] = xnxt[s];
         }
         __syncthreads();    // drains the DMA of tile+1 (vmcnt(0)) and frees this buffer
     }
