@@ -475,6 +475,8 @@ def loss_workspace(device) -> torch.Tensor:
 
 def boundary_loss_value(pred: torch.Tensor, pstride: int, bstride: int, target: torch.Tensor, B: int, H: int, W: int,
                         edge_width: int, edge_weight: float, smooth: float = 1e-6) -> torch.Tensor:
+    _require_gpu(pred, "prediction")
+    _require_gpu(target, "target")
     out = torch.empty(1, dtype=torch.float32, device=pred.device)
     ws = loss_workspace(pred.device)
     LIB.call("uh_boundary_loss", pred.data_ptr(), pstride, bstride, target.data_ptr(), B, H, W, int(edge_width),
