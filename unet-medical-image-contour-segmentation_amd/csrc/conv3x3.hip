@@ -320,7 +320,7 @@ constexpr unsigned OOB_OFFSET = 0xF0000000u;
 __device__ __forceinline__ int halo_swz(int q) { return ((q >> 2) & 1) << 1; }
 
 template <typename T, int NBW>
-__global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
+__global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes) {
@@ -337,34 +337,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lx = lane & 15, kg = lane >> 4;
-
-    int t = blockIdx.x;
-    const int txt = t % tilesX; t /= tilesX;
-    const int tyt = t % tilesY;
-    const int b = t / tilesY;
-    const int y0 = tyt * TILE, x0p = txt * TILE;
     const int co_blk = blockIdx.y * BN;
     const int co_w = co_blk + wave * (NBW * 16);
     const int Cin = C0 + C1;
     const int nchunk = Cin / CK;
+    const int ntile = B * tilesX * tilesY;
 
     // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q)
-    int pix_idx[NLOAD];
     int src_part[NLOAD];
 #pragma unroll
     for (int k = 0; k < NLOAD; ++k) {
         int p = tid + k * 256;
-        int q = p >> 2;
-        int hy = q / HALO_W, hx = q - hy * HALO_W;
-        int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-        bool ok = (p < NPIECE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pix_idx[k] = ok ? ((b * H + gy) * W + gx) : -1;
-        src_part[k] = ((p & 3) ^ halo_swz(q)) * 16;
+        src_part[k] = ((p & 3) ^ halo_swz(p >> 2)) * 16;
     }
+    auto tile_pixels = [&](int tile, int (&pix)[NLOAD]) {
+        int t = tile;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TILE, x0p = txt * TILE;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            int p = tid + k * 256;
+            int q = p >> 2;
+            int hy = q / HALO_W, hx = q - hy * HALO_W;
+            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+            bool ok = (p < NPIECE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            pix[k] = ok ? ((b * H + gy) * W + gx) : -1;
+        }
+    };
     __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, (int)x0_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 ? x1 : x0), 0, (int)(x1 ? x1_bytes : x0_bytes), 0x00020000);
 
-    auto dma_chunk = [&](int c, int bufi) {
+    auto dma_chunk = [&](const int (&pix)[NLOAD], int c, int bufi) {
         const int cc = c * CK;
         const bool first = cc < C0;
         const int ld = first ? ld0 : ld1;
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
         unsigned char* dst = lds + bufi * HALO2_BYTES + wave * 1024;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            unsigned voff = pix_idx[k] >= 0 ? (unsigned)(pix_idx[k] * ld * ES + src_part[k]) : OOB_OFFSET;
+            unsigned voff = pix[k] >= 0 ? (unsigned)(pix[k] * ld * ES + src_part[k]) : OOB_OFFSET;
             if (k < NLOAD - 1 || tid + k * 256 < NPIECE) {
                 if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
@@ -381,132 +386,176 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma_v2(
         }
     };
 
-    f32x4 acc[16][NBW];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const T* wl = w + (int64_t)(co_w + lx) * 9 * Cin + kg * VEC;
     const int64_t wnb_stride = (int64_t)16 * 9 * Cin;
 
-    dma_chunk(0, 0);
+    // Persistent over tiles: the DMA of the NEXT tile's first chunk is issued under the last chunk of the current
+    // tile, so a workgroup never waits for a cold HBM round trip after its first tile (matters for the
+    // HBM-bound 64-channel 512x512 layers, which have only 2 K-chunks per tile).
+    int pix_cur[NLOAD], pix_nxt[NLOAD];
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    tile_pixels(tile, pix_cur);
+    dma_chunk(pix_cur, 0, 0);
     u32x4 wc[3][NBW], wn[3][NBW];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int n = 0; n < NBW; ++n) wc[r][n] = *reinterpret_cast<const u32x4*>(wl + n * wnb_stride + (r * 3) * Cin);
     __syncthreads();     // drains the DMA (vmcnt(0)) before anyone reads buffer 0
+    int bufi = 0;
 
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nchunk) dma_chunk(c + 1, (c + 1) & 1);
-        const unsigned char* buf = lds + (c & 1) * HALO2_BYTES;
-        const T* wcp = wl + c * CK;
-        const T* wcp_next = wl + ((c + 1 < nchunk) ? (c + 1) : c) * CK;
+    for (; tile < ntile; tile += gridDim.x) {
+        const int next_tile = tile + gridDim.x;
+        f32x4 acc[16][NBW];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < nchunk; ++c, bufi ^= 1) {
+            if (c + 1 < nchunk) {
+                dma_chunk(pix_cur, c + 1, bufi ^ 1);
+            } else if (next_tile < ntile) {
+                tile_pixels(next_tile, pix_nxt);
+                dma_chunk(pix_nxt, 0, bufi ^ 1);
+            }
+            const unsigned char* buf = lds + bufi * HALO2_BYTES;
+            const T* wcp = wl + c * CK;
+            const T* wcp_next = wl + ((c + 1 < nchunk) ? (c + 1) : 0) * CK;      // wraps to chunk 0 of the next tile
 #pragma unroll 1
-        for (int s = 0; s < 3; ++s) {
-            // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
-            const T* wsrc = (s < 2) ? (wcp + (s + 1) * Cin) : wcp_next;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int n = 0; n < NBW; ++n)
-                    wn[r][n] = *reinterpret_cast<const u32x4*>(wsrc + n * wnb_stride + (r * 3) * Cin);
-            __builtin_amdgcn_sched_barrier(0);
-            // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
-            u32x4 xf[18];
-            auto rd = [&](int k) {
-                const int q = k * HALO_W + lx + s;
-                return *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
-            };
-            xf[0] = rd(0);
-            xf[1] = rd(1);
-            xf[2] = rd(2);
-#pragma unroll
-            for (int k = 2; k < 18; ++k) {
-                if (k + 1 < 18) xf[k + 1] = rd(k + 1);
-                __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
-                const int i = k - 2;
+            for (int s = 0; s < 3; ++s) {
+                // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
+                const T* wsrc = (s < 2) ? (wcp + (s + 1) * Cin) : wcp_next;
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) {
-                        if constexpr (ES == 2) {
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
-                        } else {
-                            f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
-                            f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+                    for (int n = 0; n < NBW; ++n)
+                        wn[r][n] = *reinterpret_cast<const u32x4*>(wsrc + n * wnb_stride + (r * 3) * Cin);
+                __builtin_amdgcn_sched_barrier(0);
+                // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
+                u32x4 xf[18];
+                auto rd = [&](int k) {
+                    const int q = k * HALO_W + lx + s;
+                    return *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
+                };
+                xf[0] = rd(0);
+                xf[1] = rd(1);
+                xf[2] = rd(2);
 #pragma unroll
-                            for (int qq = 0; qq < 4; ++qq)
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
+                for (int k = 2; k < 18; ++k) {
+                    if (k + 1 < 18) xf[k + 1] = rd(k + 1);
+                    __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
+                    const int i = k - 2;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) {
+                            if constexpr (ES == 2) {
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                            } else {
+                                f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
+                                f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+#pragma unroll
+                                for (int qq = 0; qq < 4; ++qq)
+                                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
+                            }
                         }
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int n = 0; n < NBW; ++n) wc[r][n] = wn[r][n];
-        }
-        __syncthreads();     // next chunk's DMA has landed (vmcnt(0) + barrier); this chunk's buffer is free again
-    }
-
-    // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + n*16 + kg*4 + j]; this wave holds the
-    // whole tile for its channels, so the tile statistics need only 4 shuffles per value.
-    const int gx = x0p + lx;
-    const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
-    const float inv_cnt = 1.f / (float)(vy * vx);
-    float ssum[NBW][4];
-#pragma unroll
-    for (int n = 0; n < NBW; ++n)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ssum[n][j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int gy = y0 + i;
-        const bool ok = (gy < H) && (gx < W);
-        T* yp = y + (int64_t)((b * H + gy) * W + gx) * ldy + co_w + kg * 4;
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
-                ssum[n][j] += ok ? acc[i][n][j] : 0.f;
-            }
-            if (ok) {
-                if constexpr (ES == 2) {
-                    bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
-                    *reinterpret_cast<bf16x4*>(yp + n * 16) = o;
-                } else {
-                    *reinterpret_cast<f32x4*>(yp + n * 16) = acc[i][n];
                 }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) wc[r][n] = wn[r][n];
             }
+            __syncthreads();     // the DMA issued above has landed (vmcnt(0) + barrier); this buffer is free again
         }
-    }
-    if (stats) {
+
+        // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + n*16 + kg*4 + j]; this wave holds the
+        // whole tile for its channels, so the tile statistics need only 4 shuffles per value.
+        int t = tile;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TILE, x0p = txt * TILE;
+        const int gx = x0p + lx;
+        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        const float inv_cnt = 1.f / (float)(vy * vx);
+        float ssum[NBW][4];
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) ssum[n][j] = 0.f;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) ssum[n][j] += __shfl_xor(ssum[n][j], o, 64);
-                const float mu = ssum[n][j] * inv_cnt;
-                float a = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = (y0 + i < H) && (gx < W);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool ok = (y0 + i < H) && (gx < W);
-                    float d = acc[i][n][j] - mu;
-                    a += ok ? d * d : 0.f;
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
+                    ssum[n][j] += ok ? acc[i][n][j] : 0.f;
                 }
+        }
+        // Stores go through the LDS buffer this tile has just finished reading (the other one already holds the
+        // next tile's first chunk): the MFMA layout gives each lane 4 channels of one pixel (8-byte pieces strided
+        // by the pixel pitch); re-read as 16-byte pieces, a wave writes whole pixel rows = full 128-byte lines.
+        {
+            constexpr int PITCH = BN * ES + 16;                       // +16 B: the 16 pixel lanes of a store spread over banks
+            constexpr int RP = (HALO2_BYTES / (TILE * PITCH)) >= 8 ? 8 : ((HALO2_BYTES / (TILE * PITCH)) >= 4 ? 4 : 2);
+            constexpr int PPR = BN * ES / 16;                         // 16-byte pieces per pixel
+            unsigned char* ob = lds + (bufi ^ 1) * HALO2_BYTES;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-                if (lx == 0) {
-                    const int ch = co_w + n * 16 + kg * 4 + j;
-                    stats[((int64_t)blockIdx.x * 2 + 0) * Cout + ch] = mu;
-                    stats[((int64_t)blockIdx.x * 2 + 1) * Cout + ch] = a;
+            for (int r0 = 0; r0 < 16; r0 += RP) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) {
+                        unsigned char* dst = ob + (i * TILE + lx) * PITCH + (wave * (NBW * 16) + n * 16 + kg * 4) * ES;
+                        if constexpr (ES == 2) {
+                            bf16x4 o = {(bf16_t)acc[r0 + i][n][0], (bf16_t)acc[r0 + i][n][1], (bf16_t)acc[r0 + i][n][2],
+                                        (bf16_t)acc[r0 + i][n][3]};
+                            *reinterpret_cast<bf16x4*>(dst) = o;
+                        } else {
+                            *reinterpret_cast<f32x4*>(dst) = acc[r0 + i][n];
+                        }
+                    }
+                __syncthreads();
+                for (int p = tid; p < RP * TILE * PPR; p += 256) {
+                    const int px = p / PPR, part = p - px * PPR;
+                    const int gy = y0 + r0 + (px >> 4), gxx = x0p + (px & 15);
+                    if (gy < H && gxx < W) {
+                        u32x4 v = *reinterpret_cast<const u32x4*>(ob + px * PITCH + part * 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y + (int64_t)((b * H + gy) * W + gxx) * ldy + co_blk) + part * 16) = v;
+                    }
                 }
+                __syncthreads();
             }
-        if (blockIdx.y == 0 && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
+        }
+        if (stats) {
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float mu = uh_row16_sum(ssum[n][j]) * inv_cnt;       // lanes of one kg = one DPP row
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool ok = (y0 + i < H) && (gx < W);
+                        float d = acc[i][n][j] - mu;
+                        a += ok ? d * d : 0.f;
+                    }
+                    a = uh_row16_sum(a);
+                    if (lx == 0) {
+                        const int ch = co_w + n * 16 + kg * 4 + j;
+                        stats[((int64_t)tile * 2 + 0) * Cout + ch] = mu;
+                        stats[((int64_t)tile * 2 + 1) * Cout + ch] = a;
+                    }
+                }
+            if (blockIdx.y == 0 && tid == 0) stats[(int64_t)ntile * 2 * Cout + tile] = (float)(vy * vx);
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) pix_cur[k] = pix_nxt[k];
     }
 }
 
@@ -673,12 +722,18 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         const int64_t b0 = (int64_t)B * H * W * ld0 * ES, b1 = C1 ? (int64_t)B * H * W * ld1 * ES : 0;
         if (b0 < (1ll << 31) - 4096 && b1 < (1ll << 31) - 4096) {
             // 128-channel slabs halve the halo re-reads, but small feature maps need the extra workgroups
-            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512)
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(ntile, Cout / 128), dim3(256), 0, st, x0, C0, ld0, x1,
+            // persistent workgroups: ~3 per CU (LDS 41.5 KB each) spread over the channel slabs
+            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
+                int slabs = Cout / 128, gx = (2 * 256 + slabs - 1) / slabs;       // NBW=2: 2 workgroups per CU by VGPRs
+                if (gx > ntile) gx = ntile;
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx, slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                    C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
-            else
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(ntile, Cout / 64), dim3(256), 0, st, x0, C0, ld0, x1,
+            } else {
+                int slabs = Cout / 64, gx = (3 * 256 + slabs - 1) / slabs;
+                if (gx > ntile) gx = ntile;
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx, slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                    C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
+            }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
             return UH_OK;
         }

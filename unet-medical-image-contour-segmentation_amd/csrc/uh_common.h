@@ -76,6 +76,18 @@ __device__ __forceinline__ float uh_wave_sum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16r..16r+15) with 4 DPP adds; every lane gets the total
+template <int CTRL> __device__ __forceinline__ float uh_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float uh_row16_sum(float v) {
+    v += uh_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += uh_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += uh_dpp<0x141>(v);    // row_half_mirror
+    v += uh_dpp<0x140>(v);    // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ float uh_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // softplus-form BCE-with-logits term: max(x,0) - x*t + log1p(exp(-|x|))
 __device__ __forceinline__ float uh_bce_logits(float x, float t) {
