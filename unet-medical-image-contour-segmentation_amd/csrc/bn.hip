@@ -53,18 +53,26 @@ __global__ __launch_bounds__(256) void bn_stats_fold_kernel(float* __restrict__ 
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int nfold, int L, int C, double n,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
-                                   float* __restrict__ rstd_o) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block = 64 channels x 4 fold lanes; Chan merge in double, then the affine coefficients and running statistics
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int nfold, int L, int C,
+                                                          double n, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float momentum, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+    __shared__ double red[3][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const float* cnt = stats + (int64_t)nslab * 2 * C + (L > 1 ? nslab : 0);
     Moments m = {0.0, 0.0, 0.0};
-    for (int f = 0; f < nfold; ++f)
-        chan_merge(m, (double)cnt[f], (double)stats[((int64_t)f * L * 2 + 0) * C + c],
-                   (double)stats[((int64_t)f * L * 2 + 1) * C + c]);
+    if (c < C)
+        for (int f = sl; f < nfold; f += 4)
+            chan_merge(m, (double)cnt[f], (double)stats[((int64_t)f * L * 2 + 0) * C + c],
+                       (double)stats[((int64_t)f * L * 2 + 1) * C + c]);
+    red[0][sl][cl] = m.n; red[1][sl][cl] = m.mean; red[2][sl][cl] = m.m2;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    for (int k = 1; k < 4; ++k) chan_merge(m, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
     double mean = m.mean;
     double var = m.m2 / n;                      // biased
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -89,13 +97,14 @@ extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int6
     hipStream_t st = (hipStream_t)stream;
     int L = 1, nfold = nslab;
     if (nslab > 64) {
-        L = (nslab + 63) / 64;
+        L = (nslab + 127) / 128;
+        if (L < 2) L = 2;
         nfold = (nslab + L - 1) / L;
         hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + 63) / 64, nfold), dim3(256), 0, st, (float*)stat_partials,
                            nslab, C, L);
         UH_CHECK_LAUNCH("bn_stats_fold_kernel");
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stat_partials, nslab, nfold, L, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stat_partials, nslab, nfold, L, C,
                        (double)n, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
     return UH_OK;

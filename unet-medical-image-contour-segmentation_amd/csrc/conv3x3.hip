@@ -18,7 +18,7 @@
 //                       (deterministic, no atomics).
 //   conv3x3_wgrad_stem / _generic
 // Backward-data is conv3x3_fwd with the flipped/transposed filter produced by uh_pack_w3x3.
-#include "uh_common.h"
+#include "uh_vec.h"
 
 // =====================================================================================
 // weight (un)packing
@@ -639,6 +639,126 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem(const T* __restrict__ x,
 }
 
 // =====================================================================================
+// forward, stem v2 (Cin <= 4, Cout % V == 0): thread = (pixel lane, V consecutive output channels) so every
+// store is a 16-byte piece of a full pixel row; 16x16 tile per workgroup, halo + filters in LDS.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_fwd_stem_v2(const T* __restrict__ x, int Cin, int ldx,
+                                                           const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout,
+                                                           float* __restrict__ stats, int B, int H, int W, int tilesX,
+                                                           int tilesY) {
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int PPT = 8;                       // pixels per thread per pass (256 px / 32 pixel lanes)
+    extern __shared__ float sm[];                // xs[324*4] | ws[9*4*CG] | red[4][CG]
+    const int G = Cout / V;                      // channel groups
+    const int GB = G < 8 ? G : 8;                // groups per pass (8 x V channels)
+    const int CG = GB * V;
+    float* xs = sm;
+    float* ws = sm + HALO_PIX * 4;
+    float* red = ws + 36 * CG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int txt = t % tilesX; t /= tilesX;
+    const int tyt = t % tilesY;
+    const int b = t / tilesY;
+    const int y0 = tyt * TILE, x0p = txt * TILE;
+    const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+    for (int idx = tid; idx < HALO_PIX * 4; idx += 256) {
+        int q = idx >> 2, ci = idx & 3;
+        int hy = q / HALO_W, hx = q - hy * HALO_W;
+        int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+        float v = 0.f;
+        if (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
+        xs[idx] = v;
+    }
+    const int g = tid % GB, pl = tid / GB;       // pl in [0, 256/GB)
+    const int PL = 256 / GB;
+    for (int cb = 0; cb < Cout; cb += CG) {
+        __syncthreads();
+        for (int idx = tid; idx < 36 * CG; idx += 256) {          // ws[(tap*4+ci)*CG + c]
+            int c = idx % CG, tc = idx / CG, tap = tc >> 2, ci = tc & 3;
+            ws[idx] = (ci < Cin && cb + c < Cout) ? uh_to_f32(w[((int64_t)(cb + c) * 9 + tap) * Cin + ci]) : 0.f;
+        }
+        __syncthreads();
+        const bool cok = cb + g * V < Cout;
+        float acc[PPT][V];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[j][i] = 0.f;
+        if (pl < PL) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = tap / 3, s = tap - 3 * r;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    float wv[V];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) wv[i] = ws[(tap * 4 + ci) * CG + g * V + i];
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        const int px = pl + j * PL;             // PL * PPT >= 256 when GB == 8
+                        if (px < 256) {
+                            const float xv = xs[(((px >> 4) + r) * HALO_W + (px & 15) + s) * 4 + ci];
+#pragma unroll
+                            for (int i = 0; i < V; ++i) acc[j][i] = fmaf(xv, wv[i], acc[j][i]);
+                        }
+                    }
+                }
+            }
+        }
+        float s1[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) s1[i] = 0.f;
+        if (pl < PL && cok) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int px = pl + j * PL;
+                const int ty = px >> 4, tx = px & 15;
+                const bool ok = px < 256 && ty < vy && tx < vx;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    acc[j][i] = uh_round_as<T>(acc[j][i]);
+                    s1[i] += ok ? acc[j][i] : 0.f;
+                }
+                if (ok) uh_store<T, V>(y + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + cb + g * V, acc[j]);
+            }
+        }
+        if (stats) {
+            // per-channel tile statistics: reduce over the pixel lanes (threads with equal g) through LDS
+            for (int pass = 0; pass < 2; ++pass) {
+                __syncthreads();
+                for (int idx = tid; idx < CG; idx += 256) red[idx] = 0.f;
+                __syncthreads();
+                if (pl < PL && cok) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) atomicAdd(&red[g * V + i], s1[i]);      // LDS atomics, 32 adders per address
+                }
+                __syncthreads();
+                if (pass == 0) {
+                    const float inv = 1.f / (float)(vy * vx);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const float mu = red[g * V + i] * inv;
+                        float a = 0.f;
+#pragma unroll
+                        for (int j = 0; j < PPT; ++j) {
+                            const int px = pl + j * PL;
+                            const bool ok = px < 256 && (px >> 4) < vy && (px & 15) < vx;
+                            const float d = acc[j][i] - mu;
+                            a += ok ? d * d : 0.f;
+                        }
+                        s1[i] = a;
+                    }
+                    if (tid < CG && cb + tid < Cout) stats[((int64_t)blockIdx.x * 2 + 0) * Cout + cb + tid] = red[tid] * inv;
+                } else if (tid < CG && cb + tid < Cout) {
+                    stats[((int64_t)blockIdx.x * 2 + 1) * Cout + cb + tid] = red[tid];
+                }
+            }
+        }
+    }
+    if (stats && tid == 0) stats[(int64_t)gridDim.x * 2 * Cout + blockIdx.x] = (float)(vy * vx);
+}
+
+// =====================================================================================
 // forward, generic (any channel counts)
 // =====================================================================================
 template <typename T>
@@ -748,6 +868,15 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         return UH_OK;
     }
     if (Cin <= 4 && C1 == 0) {
+        constexpr int V = 16 / ES;
+        if (Cout % V == 0 && uh_aligned16(y) && (ldy * ES) % 16 == 0) {
+            int G = Cout / V, GB = G < 8 ? G : 8, CG = GB * V;
+            size_t sm = (size_t)(HALO_PIX * 4 + 36 * CG + CG) * sizeof(float);
+            hipLaunchKernelGGL(conv3x3_fwd_stem_v2<T>, dim3(ntile), dim3(256), sm, st, x0, Cin, ld0, w, y, ldy, Cout, stats,
+                               B, H, W, tilesX, tilesY);
+            UH_CHECK_LAUNCH("conv3x3_fwd_stem_v2");
+            return UH_OK;
+        }
         hipLaunchKernelGGL(conv3x3_fwd_stem<T>, dim3(ntile), dim3(256), 0, st, x0, Cin, ld0, w, y, ldy, Cout, stats, B, H,
                            W, tilesX, tilesY);
         UH_CHECK_LAUNCH("conv3x3_fwd_stem");
@@ -1187,6 +1316,72 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem(const T* __restrict__ 
     }
 }
 
+// ---- stem wgrad v2 (Cin <= 4, Cout % V == 0): thread = (pixel lane, V output channels); dy is streamed once with
+// 16-byte loads, the 9 input taps are scalar (cache resident); one input channel per blockIdx.z.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v2(const T* __restrict__ dy, int lddy, const T* __restrict__ x,
+                                                             int Cin, int ldx, float* __restrict__ slabs, int Cout, int B,
+                                                             int H, int W, int nsplit) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ float red[4][9][64];              // [wave][tap][channel in pass]
+    const int G = Cout / V;
+    const int GB = G < 8 ? G : 8;
+    const int PL = 256 / GB;
+    const int tid = threadIdx.x, g = tid % GB, pl = tid / GB;
+    const int ci = blockIdx.z;
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t p0 = npix * blockIdx.x / nsplit, p1 = npix * (blockIdx.x + 1) / nsplit;
+    float* slab = slabs + (int64_t)blockIdx.x * Cout * 9 * Cin;
+    for (int cb = 0; cb < Cout; cb += GB * V) {
+        const bool cok = pl < PL && cb + g * V < Cout;
+        float acc[9][V];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
+        if (cok)
+            for (int64_t p = p0 + pl; p < p1; p += PL) {
+                const int wx = (int)(p % W);
+                const int hy = (int)((p / W) % H);
+                float d[V];
+                uh_load<T, V>(dy + p * lddy + cb + g * V, d);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int yy = hy + r - 1, xx = wx + s - 1;
+                        float xv = 0.f;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                            xv = uh_to_f32(x[(p + (int64_t)(r - 1) * W + (s - 1)) * ldx + ci]);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[r * 3 + s][i] = fmaf(d[i], xv, acc[r * 3 + s][i]);
+                    }
+            }
+        // reduce over pixel lanes: lanes of a wave with equal g differ in bits >= log2(GB)
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float v = acc[k][i];
+                for (int o = GB; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                acc[k][i] = v;
+            }
+        __syncthreads();
+        if ((tid & 63) < GB && pl < PL) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int i = 0; i < V; ++i) red[tid >> 6][k][g * V + i] = acc[k][i];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 9 * GB * V; idx += 256) {
+            const int k = idx / (GB * V), c = idx - k * (GB * V);
+            if (cb + c < Cout)
+                slab[((int64_t)(cb + c) * 9 + k) * Cin + ci] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+        }
+    }
+}
+
 // ---- generic wgrad: one block per (co, tap); threads stride over ci; serial over pixels
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_generic(const T* __restrict__ dy, int lddy, const T* __restrict__ x0,
@@ -1247,8 +1442,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned
         p.kind = 1;
         p.tilesX = (W + TILE - 1) / TILE; p.tilesY = (H + TILE - 1) / TILE;
         p.ntile = B * p.tilesX * p.tilesY;
-        int cg = (Cout + 63) / 64;
-        int want = (512 + cg - 1) / cg;
+        int want = 1024;
         p.nsplit = want > p.ntile ? p.ntile : want;
     } else {
         p.kind = 2; p.nsplit = 0; p.tilesX = p.tilesY = p.ntile = 0;
@@ -1304,9 +1498,16 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             UH_CHECK_LAUNCH("conv3x3_wgrad_mfma");
         }
     } else {
-        hipLaunchKernelGGL(conv3x3_wgrad_stem<T>, dim3(p.nsplit, (Cout + 63) / 64), dim3(256), 0, st, dy, lddy, x0, Cin,
-                           ld0, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
-        UH_CHECK_LAUNCH("conv3x3_wgrad_stem");
+        constexpr int V = 16 / ES;
+        if (Cout % V == 0 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {
+            hipLaunchKernelGGL(conv3x3_wgrad_stem_v2<T>, dim3(p.nsplit, 1, Cin), dim3(256), 0, st, dy, lddy, x0, Cin, ld0,
+                               slabs, Cout, B, H, W, p.nsplit);
+            UH_CHECK_LAUNCH("conv3x3_wgrad_stem_v2");
+        } else {
+            hipLaunchKernelGGL(conv3x3_wgrad_stem<T>, dim3(p.nsplit, (Cout + 63) / 64), dim3(256), 0, st, dy, lddy, x0, Cin,
+                               ld0, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+            UH_CHECK_LAUNCH("conv3x3_wgrad_stem");
+        }
     }
     int64_t n = (int64_t)Cout * 9 * Cin;      // multiple of 4 on every slab path (Cout % 64 == 0 or 9*... stem: Cout*9*Cin)
     if (n % 4 != 0 || !uh_aligned16(dw) || !uh_aligned16(slabs))

@@ -124,6 +124,18 @@ def _empty_like_param(p: torch.Tensor) -> torch.Tensor:
     return torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=p.device)
 
 
+# FusedRMSprop registers, per parameter storage, the view of its flat gradient buffer that the backward kernels
+# should write into directly (no gather copy afterwards).  Keyed by data_ptr of the parameter.
+GRAD_DST = {}
+
+
+def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
+    dst = GRAD_DST.get(p.data_ptr())
+    if dst is not None and dst.shape == p.shape and dst.stride() == p.stride():
+        return dst
+    return _empty_like_param(p)
+
+
 def _is_krsc_dense(w: torch.Tensor) -> bool:
     O, I, kh, kw = w.shape
     return w.stride() == (kh * kw * I, 1, kw * I, I)
@@ -257,6 +269,7 @@ class ConvBnReluFn(Function):
         LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
                  n, Cout, _dt(y), _stream())
         ctx.save_for_backward(x0, x1, y, coef, wd, weight)
+        ctx.bn_params = (gamma, beta)
         ctx.training = training
         ctx.dims = (B, H, W, C0, C1, Cout)
         return z
@@ -277,8 +290,8 @@ class ConvBnReluFn(Function):
         partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
         LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
-        dgb = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
-        dgamma, dbeta = dgb[:Cout], dgb[Cout:]
+        gamma_p, beta_p = ctx.bn_params
+        dgamma, dbeta = _grad_buffer(gamma_p), _grad_buffer(beta_p)
         dy = torch.empty_like(y)
         LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
@@ -286,7 +299,7 @@ class ConvBnReluFn(Function):
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
         dweight = None
         if ctx.needs_input_grad[2]:
-            dweight = _empty_like_param(weight)
+            dweight = _grad_buffer(weight)
             if _is_krsc_dense(weight):
                 conv3x3_wgrad(dy, x0, x1, dweight)
             else:

@@ -74,6 +74,7 @@ class FusedRMSprop:
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(LIB.query("uh_optim_ws_bytes", off), dtype=torch.uint8, device=dev)
         self._index = {}
+        self._grad_keys = []
         with torch.no_grad():
             for i, (p, (o, n)) in enumerate(zip(self.params, slices)):
                 if p.dtype != torch.float32:
@@ -84,17 +85,24 @@ class FusedRMSprop:
                 view.copy_(p)
                 p.data = view
                 self._index[id(p)] = i
+                # backward kernels write this parameter's gradient straight into the flat buffer (ops.GRAD_DST)
+                ops.GRAD_DST[view.data_ptr()] = torch.as_strided(self.flat_g, p.shape, p.stride(), o)
+                self._grad_keys.append(view.data_ptr())
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.sync = None
         if dpmod.world_size(process_group) > 1:
             self.sync = dpmod.BucketedGradSync(self.flat_g, slices, bucket_bytes, process_group)
 
+    def __del__(self):
+        for k in getattr(self, "_grad_keys", []):
+            ops.GRAD_DST.pop(k, None)
+
     def _on_grad(self, p: torch.Tensor):
         i = self._index[id(p)]
         o, n = self.slices[i]
         g = p.grad
-        dst = torch.as_strided(self.flat_g, p.shape, p.stride(), o)
-        dst.copy_(g)
+        if g.data_ptr() != self.flat_g.data_ptr() + 4 * o:          # not already written in place by the kernel
+            torch.as_strided(self.flat_g, p.shape, p.stride(), o).copy_(g)
         p.grad = None
         if self.sync is not None:
             self.sync.mark_ready(i)
