@@ -188,7 +188,9 @@ def _run_traj(name, cls, args, n_classes, lr=1e-5, bmc=None, widths=None):
         else:
             # parameters moved by 3 sign-like RMSprop steps of size ~10*lr: round-off on near-zero
             # gradients may flip individual updates (same allowance as tests/test_oracle_golden.py)
-            check(v, final[k], 5e-3, "final " + k, atol=0.0 if "running" in k else 60 * lr)
+            # momentum 0.999 accumulates the +-10 sign-like steps: 10 + 20 + 30 = 60*lr of travel in 3 steps, so one
+            # weight whose tiny gradient flips sign in all three steps ends up to 120*lr away
+            check(v, final[k], 5e-3, "final " + k, atol=0.0 if "running" in k else 150 * lr)
 
 
 def test_unet_t_bilinear_trajectory():

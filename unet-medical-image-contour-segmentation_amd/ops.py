@@ -129,11 +129,13 @@ def _empty_like_param(p: torch.Tensor) -> torch.Tensor:
 GRAD_DST = {}
 
 
-def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
-    dst = GRAD_DST.get(p.data_ptr())
-    if dst is not None and dst.shape == p.shape and dst.stride() == p.stride():
-        return dst
-    return _empty_like_param(p)
+def _grad_buffer(p: torch.Tensor):
+    """-> (buffer to write the gradient of `p` into, completion callback or None).  With a callback the gradient is
+    final in the optimizer's flat buffer: the autograd node returns None for it (no AccumulateGrad clone)."""
+    ent = GRAD_DST.get(p.data_ptr())
+    if ent is not None and ent[0].shape == p.shape and ent[0].stride() == p.stride():
+        return ent
+    return _empty_like_param(p), None
 
 
 def _is_krsc_dense(w: torch.Tensor) -> bool:
@@ -291,7 +293,7 @@ class ConvBnReluFn(Function):
         LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
         gamma_p, beta_p = ctx.bn_params
-        dgamma, dbeta = _grad_buffer(gamma_p), _grad_buffer(beta_p)
+        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
         dy = torch.empty_like(y)
         LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
@@ -299,7 +301,7 @@ class ConvBnReluFn(Function):
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
         dweight = None
         if ctx.needs_input_grad[2]:
-            dweight = _grad_buffer(weight)
+            dweight, cb_w = _grad_buffer(weight)
             if _is_krsc_dense(weight):
                 conv3x3_wgrad(dy, x0, x1, dweight)
             else:
@@ -307,6 +309,15 @@ class ConvBnReluFn(Function):
                 conv3x3_wgrad(dy, x0, x1, dwk)
                 sO, sI, sH, sW = dweight.stride()
                 LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
+            if cb_w is not None:
+                cb_w()
+                dweight = None
+        if cb_g is not None:
+            cb_g()
+            dgamma = None
+        if cb_b is not None:
+            cb_b()
+            dbeta = None
         dx0 = dx1 = None
         if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False)

@@ -86,7 +86,8 @@ class FusedRMSprop:
                 p.data = view
                 self._index[id(p)] = i
                 # backward kernels write this parameter's gradient straight into the flat buffer (ops.GRAD_DST)
-                ops.GRAD_DST[view.data_ptr()] = torch.as_strided(self.flat_g, p.shape, p.stride(), o)
+                ops.GRAD_DST[view.data_ptr()] = (torch.as_strided(self.flat_g, p.shape, p.stride(), o),
+                                                 _weak_callback(self, i))
                 self._grad_keys.append(view.data_ptr())
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.sync = None
@@ -97,12 +98,17 @@ class FusedRMSprop:
         for k in getattr(self, "_grad_keys", []):
             ops.GRAD_DST.pop(k, None)
 
+    def _written(self, i: int):
+        if self.sync is not None:
+            self.sync.mark_ready(i)
+
     def _on_grad(self, p: torch.Tensor):
         i = self._index[id(p)]
         o, n = self.slices[i]
         g = p.grad
-        if g.data_ptr() != self.flat_g.data_ptr() + 4 * o:          # not already written in place by the kernel
-            torch.as_strided(self.flat_g, p.shape, p.stride(), o).copy_(g)
+        if g is None:            # written in place by the backward kernel (ops.GRAD_DST); readiness came via _written
+            return
+        torch.as_strided(self.flat_g, p.shape, p.stride(), o).copy_(g)     # parameters without an in-place writer
         p.grad = None
         if self.sync is not None:
             self.sync.mark_ready(i)
@@ -128,6 +134,17 @@ class FusedRMSprop:
         """The (clipped, after step()) gradient of `p` as stored in the flat buffer."""
         o, n = self.slices[self._index[id(p)]]
         return torch.as_strided(self.flat_g, p.shape, p.stride(), o)
+
+
+def _weak_callback(opt: "FusedRMSprop", i: int):
+    import weakref
+    ref = weakref.ref(opt)
+
+    def cb():
+        o = ref()
+        if o is not None:
+            o._written(i)
+    return cb
 
 
 def _is_dense(p: torch.Tensor) -> bool:
