@@ -1143,31 +1143,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     const int t_begin = (int)(((int64_t)ntile * split) / nsplit);
     const int t_end = (int)(((int64_t)ntile * (split + 1)) / nsplit);
 
+    // per-thread DMA geometry that does not depend on the tile: halo coordinates of each 16-byte unit and its byte
+    // offset relative to the tile's top-left halo pixel (tile-dependent part is one scalar base + 4 range checks)
+    int xg[6], xo[6], dg[4], dof[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int p = tid + k * 256;
+        const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+        const int hy = q / HALO_W, hx = q - hy * HALO_W;
+        xg[k] = (p < XUNITS) ? ((hy << 8) | hx) : -1;
+        xo[k] = (hy * W + hx) * ldx * 2 + u * 16;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = tid + k * 256;
+        const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+        dg[k] = ((q >> 4) << 8) | (q & 15);
+        dof[k] = ((q >> 4) * W + (q & 15)) * lddy * 2 + u * 16;
+    }
     auto issue = [&](int tile, int bufi) {
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
         const int tyt = t % tilesY;
         const int b = t / tilesY;
         const int y0 = tyt * TH, x0p = txt * TILE;
+        const int xbase = ((b * H + y0 - 1) * W + x0p - 1) * ldx * 2;     // may be "negative": only used when in range
+        const int dbase = ((b * H + y0) * W + x0p) * lddy * 2;
         unsigned char* xb = lds + bufi * STAGE + wave * 1024;
         unsigned char* db = xb + XBYTES;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const int p = tid + k * 256;
-            const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
-            const int hy = q / HALO_W, hx = q - hy * HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            unsigned voff = ok ? (unsigned)(((b * H + gy) * W + gx) * ldx * 2 + u * 16) : OOB_OFFSET;
-            if (k < 5 || p < XUNITS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
+            const int gy = y0 - 1 + (xg[k] >> 8), gx = x0p - 1 + (xg[k] & 255);
+            const bool ok = xg[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            unsigned voff = ok ? (unsigned)(xbase + xo[k]) : OOB_OFFSET;
+            if (k < 5 || xg[k] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int p = tid + k * 256;
-            const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
-            const int gy = y0 + (q >> 4), gx = x0p + (q & 15);
+            const int gy = y0 + (dg[k] >> 8), gx = x0p + (dg[k] & 255);
             const bool ok = gy < H && gx < W;
-            unsigned voff = ok ? (unsigned)(((b * H + gy) * W + gx) * lddy * 2 + u * 16) : OOB_OFFSET;
+            unsigned voff = ok ? (unsigned)(dbase + dof[k]) : OOB_OFFSET;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(db + k * 4096), 16, voff, 0, 0, 0);
         }
     };
