@@ -14,95 +14,149 @@ static inline unsigned ct_grid(int64_t total) {
 }
 
 // ------------------------------------------------------------------------------------ ConvTranspose 2x2
-// thread = (output pixel, 4 consecutive output channels); weights read as W[i][o][r][s] fp32
-template <typename T>
-__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, T* __restrict__ y, int ldy,
-                                                           int B, int h, int wd, int Cin, int Cout, int Ho, int Wo,
-                                                           int pt, int pl) {
-    const int64_t total = (int64_t)B * Ho * Wo * Cout;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int o = (int)(idx % Cout);
-        int64_t p = idx / Cout;
-        int ox = (int)(p % Wo);
-        int oy = (int)((p / Wo) % Ho);
-        int b = (int)(p / ((int64_t)Wo * Ho));
-        int uy = oy - pt, ux = ox - pl;
-        float acc = 0.f;
-        if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * wd) {
-            int hy = uy >> 1, r = uy & 1, hx = ux >> 1, s = ux & 1;
-            const T* xp = x + ((int64_t)(b * h + hy) * wd + hx) * ldx;
-            const float* wp = w + (int64_t)o * 4 + r * 2 + s;
-            acc = bias[o];
-            for (int i = 0; i < Cin; ++i) acc = fmaf(uh_to_f32(xp[i]), wp[(int64_t)i * Cout * 4], acc);
-        }
-        y[p * ldy + o] = uh_from_f32<T>(acc);
-    }
+// Three GEMMs over pixels on a shared LDS-tiled SIMT kernel (64x64 tile, 16-deep K steps, 4x4 outputs per thread,
+// fp32 accumulate); the operand / result addressing is supplied by small functors:
+//   fwd   y[(p,rs)][o] = bias[o] + sum_i x[p][i] * W[i][o][rs]          M = pixels, N = 4*Cout, K = Cin
+//   dgrad dx[p][i]     = sum_{rs,o} dy[(p,rs)][o] * W[i][o][rs]         M = pixels, N = Cin,    K = 4*Cout
+//   wgrad dW[i][o][rs] = sum_p x[p][i] * dy[(p,rs)][o]                  M = Cin,    N = 4*Cout, K = pixels (split)
+// (p,rs) = output pixel (2h+r+pad_top, 2w+s+pad_left) of input pixel p; out-of-range ones (negative pad = crop)
+// contribute zeros.  Config 5 only; an MFMA version is the obvious next step.
+struct CtGeom { int B, h, w, Ho, Wo, pt, pl, Cin, Cout; };
+
+__device__ __forceinline__ int64_t ct_out_pixel(const CtGeom& g, int64_t p, int rs) {
+    int hx = (int)(p % g.w);
+    int hy = (int)((p / g.w) % g.h);
+    int b = (int)(p / ((int64_t)g.w * g.h));
+    int oy = 2 * hy + (rs >> 1) + g.pt, ox = 2 * hx + (rs & 1) + g.pl;
+    if (oy < 0 || oy >= g.Ho || ox < 0 || ox >= g.Wo) return -1;
+    return ((int64_t)b * g.Ho + oy) * g.Wo + ox;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void convt2x2_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w,
-                                                             T* __restrict__ dx, int lddx, int B, int h, int wd, int Cin,
-                                                             int Cout, int Ho, int Wo, int pt, int pl) {
-    const int64_t total = (int64_t)B * h * wd * Cin;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int i = (int)(idx % Cin);
-        int64_t p = idx / Cin;
-        int hx = (int)(p % wd);
-        int hy = (int)((p / wd) % h);
-        int b = (int)(p / ((int64_t)wd * h));
-        float acc = 0.f;
-        const float* wp = w + (int64_t)i * Cout * 4;
+template <typename T> struct CtFwd {
+    const T* x; int ldx; const float* w; const float* bias; T* y; int ldy; CtGeom g;
+    __device__ float A(int64_t m, int k) const { return uh_to_f32(x[m * ldx + k]); }
+    __device__ float Bv(int k, int n) const { int rs = n / g.Cout, o = n - rs * g.Cout; return w[((int64_t)k * g.Cout + o) * 4 + rs]; }
+    __device__ void C(int64_t m, int n, float v, int) const {
+        int rs = n / g.Cout, o = n - rs * g.Cout;
+        int64_t q = ct_out_pixel(g, m, rs);
+        if (q >= 0) y[q * ldy + o] = uh_from_f32<T>(v + bias[o]);
+    }
+};
+template <typename T> struct CtDgrad {
+    const T* dy; int lddy; const float* w; T* dx; int lddx; CtGeom g;
+    __device__ float A(int64_t m, int k) const {
+        int rs = k / g.Cout, o = k - rs * g.Cout;
+        int64_t q = ct_out_pixel(g, m, rs);
+        return q >= 0 ? uh_to_f32(dy[q * lddy + o]) : 0.f;
+    }
+    __device__ float Bv(int k, int n) const { int rs = k / g.Cout, o = k - rs * g.Cout; return w[((int64_t)n * g.Cout + o) * 4 + rs]; }
+    __device__ void C(int64_t m, int n, float v, int) const { dx[m * lddx + n] = uh_from_f32<T>(v); }
+};
+template <typename T> struct CtWgrad {
+    const T* x; int ldx; const T* dy; int lddy; float* slabs; CtGeom g;
+    // M index = input channel i, K index = pixel (offset by the split's first pixel in the kernel)
+    __device__ float A(int64_t m, int64_t k) const { return uh_to_f32(x[k * ldx + m]); }
+    __device__ float Bv(int64_t k, int n) const {
+        int rs = n / g.Cout, o = n - rs * g.Cout;
+        int64_t q = ct_out_pixel(g, k, rs);
+        return q >= 0 ? uh_to_f32(dy[q * lddy + o]) : 0.f;
+    }
+    __device__ void C(int64_t m, int n, float v, int split) const {
+        int rs = n / g.Cout, o = n - rs * g.Cout;
+        slabs[(int64_t)split * ((int64_t)g.Cin * g.Cout * 4) + ((int64_t)m * g.Cout + o) * 4 + rs] = v;
+    }
+};
+
+template <typename F>
+__global__ __launch_bounds__(256) void ct_gemm_kernel(F f, int64_t M, int N, int64_t K, int nsplit) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int split = blockIdx.z;
+    const int64_t k_begin = K * split / nsplit, k_end = K * (split + 1) / nsplit;
+    float acc[4][4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                int oy = 2 * hy + r + pt, ox = 2 * hx + s + pl;
-                if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-                const T* g = dy + ((int64_t)(b * Ho + oy) * Wo + ox) * lddy;
-                for (int o = 0; o < Cout; ++o) acc = fmaf(uh_to_f32(g[o]), wp[o * 4 + r * 2 + s], acc);
-            }
-        dx[p * lddx + i] = uh_from_f32<T>(acc);
-    }
-}
-
-// block = one (i-range, tap) over a pixel split; threads = output channels; partial slabs then reduce
-template <typename T>
-__global__ __launch_bounds__(256) void convt2x2_wgrad_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x,
-                                                             int ldx, float* __restrict__ slabs, int B, int h, int wd,
-                                                             int Cin, int Cout, int Ho, int Wo, int pt, int pl, int nsplit) {
-    // grid: x = Cin*4 (i, r, s), y = split
-    const int i = blockIdx.x >> 2, rs = blockIdx.x & 3, r = rs >> 1, s = rs & 1;
-    const int split = blockIdx.y;
-    const int64_t npix = (int64_t)B * h * wd;
-    const int64_t p0 = npix * split / nsplit, p1 = npix * (split + 1) / nsplit;
-    float* slab = slabs + (int64_t)split * ((int64_t)Cin * Cout * 4 + Cout);
-    for (int o = threadIdx.x; o < Cout; o += 256) {
-        float acc = 0.f, bsum = 0.f;
-        for (int64_t p = p0; p < p1; ++p) {
-            int hx = (int)(p % wd);
-            int hy = (int)((p / wd) % h);
-            int b = (int)(p / ((int64_t)wd * h));
-            int oy = 2 * hy + r + pt, ox = 2 * hx + s + pl;
-            if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-            float g = uh_to_f32(dy[((int64_t)(b * Ho + oy) * Wo + ox) * lddy + o]);
-            acc = fmaf(uh_to_f32(x[p * ldx + i]), g, acc);
-            bsum += g;
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += 16) {
+        // 64x16 elements of A and of B: 4 each per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int idx = threadIdx.x + e * 256;
+            int kk = idx & 15, mm = idx >> 4;
+            int64_t k = k0 + kk, m = m0 + mm;
+            As[kk][mm] = (k < k_end && m < M) ? f.A(m, k) : 0.f;
+            int n = n0 + mm;
+            Bs[kk][mm] = (k < k_end && n < N) ? f.Bv(k, n) : 0.f;
         }
-        slab[((int64_t)i * Cout + o) * 4 + rs] = acc;
-        if (i == 0) atomicAdd(&slab[(int64_t)Cin * Cout * 4 + o], bsum);   // 4 taps add into the bias slot
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t m = m0 + ty * 4 + i;
+            int n = n0 + tx * 4 + j;
+            if (m < M && n < N) f.C(m, n, acc[i][j], split);
+        }
 }
 
-__global__ void convt_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, float* __restrict__ dbias,
-                                         int64_t nw, int Cout, int nsplit) {
+// zero fill (used when F.pad leaves a border around the up-sampled image)
+template <typename T>
+__global__ void ct_zero_kernel(T* y, int ldy, int64_t npix, int C) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = nw + Cout;
-    if (idx >= stride) return;
+    if (idx >= npix * C) return;
+    y[(idx / C) * ldy + (idx % C)] = uh_from_f32<T>(0.f);
+}
+
+// dbias[o] += sum over the up-sampled region of dy[.., o]; grid = (64-channel slabs, pixel slices); one fp32 atomic
+// per (block, channel) into the zero-initialised dbias
+template <typename T>
+__global__ __launch_bounds__(256) void ct_dbias_kernel(const T* __restrict__ dy, int lddy, CtGeom g, float* __restrict__ dbias) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    const int y_lo = max(g.pt, 0), y_hi = min(g.pt + 2 * g.h, g.Ho), x_lo = max(g.pl, 0), x_hi = min(g.pl + 2 * g.w, g.Wo);
+    const int rw = x_hi - x_lo, rh = y_hi - y_lo;
+    const int64_t n = (int64_t)g.B * rh * rw;
+    if (o < g.Cout && rw > 0 && rh > 0)
+        for (int64_t p = (int64_t)blockIdx.y * 4 + sl; p < n; p += (int64_t)gridDim.y * 4) {
+            int xx = (int)(p % rw) + x_lo;
+            int yy = (int)((p / rw) % rh) + y_lo;
+            int b = (int)(p / ((int64_t)rw * rh));
+            acc += uh_to_f32(dy[(((int64_t)b * g.Ho + yy) * g.Wo + xx) * lddy + o]);
+        }
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0 && o < g.Cout) atomicAdd(&dbias[o], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ void convt_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t nw, int nsplit) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nw) return;
     float v = 0.f;
-    for (int k = 0; k < nsplit; ++k) v += slabs[(int64_t)k * stride + idx];
-    if (idx < nw) dw[idx] = v;
-    else dbias[idx - nw] = v;
+    for (int k = 0; k < nsplit; ++k) v += slabs[(int64_t)k * nw + idx];
+    dw[idx] = v;
+}
+
+static inline CtGeom ct_geom(int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int pt, int pl) {
+    CtGeom g; g.B = B; g.h = h; g.w = w_; g.Ho = Ho; g.Wo = Wo; g.pt = pt; g.pl = pl; g.Cin = Cin; g.Cout = Cout;
+    return g;
 }
 
 extern "C" int uh_convt2x2_fwd(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int h,
@@ -111,12 +165,20 @@ extern "C" int uh_convt2x2_fwd(const void* x, int ldx, const float* w, const flo
     UH_REQUIRE(x && w && bias && y && B > 0 && h > 0 && w_ > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout,
                "uh_convt2x2_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    int64_t total = (int64_t)B * Ho * Wo * Cout;
+    CtGeom g = ct_geom(B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
+    const int64_t M = (int64_t)B * h * w_;
+    const bool border = !(pad_top == 0 && pad_left == 0 && Ho == 2 * h && Wo == 2 * w_);
     UH_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL(convt2x2_fwd_kernel<T>, dim3(ct_grid(total)), dim3(256), 0, st, (const T*)x, ldx, w, bias, (T*)y,
-                           ldy, B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
+        if (border) {
+            int64_t tot = (int64_t)B * Ho * Wo * Cout;
+            hipLaunchKernelGGL(ct_zero_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (T*)y, ldy,
+                               (int64_t)B * Ho * Wo, Cout);
+        }
+        CtFwd<T> f{(const T*)x, ldx, w, bias, (T*)y, ldy, g};
+        hipLaunchKernelGGL(ct_gemm_kernel<CtFwd<T>>, dim3((unsigned)((M + 63) / 64), (4 * Cout + 63) / 64, 1), dim3(256), 0, st,
+                           f, M, 4 * Cout, (int64_t)Cin, 1);
     });
-    UH_CHECK_LAUNCH("convt2x2_fwd_kernel");
+    UH_CHECK_LAUNCH("convt2x2_fwd");
     return UH_OK;
 }
 
@@ -125,26 +187,29 @@ extern "C" int uh_convt2x2_dgrad(const void* dy, int lddy, const float* w, void*
     UH_REQUIRE(dy && w && dx && B > 0 && h > 0 && w_ > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin,
                "uh_convt2x2_dgrad: bad args");
     hipStream_t st = (hipStream_t)stream;
-    int64_t total = (int64_t)B * h * w_ * Cin;
+    CtGeom g = ct_geom(B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
+    const int64_t M = (int64_t)B * h * w_;
     UH_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL(convt2x2_dgrad_kernel<T>, dim3(ct_grid(total)), dim3(256), 0, st, (const T*)dy, lddy, w, (T*)dx,
-                           lddx, B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
+        CtDgrad<T> f{(const T*)dy, lddy, w, (T*)dx, lddx, g};
+        hipLaunchKernelGGL(ct_gemm_kernel<CtDgrad<T>>, dim3((unsigned)((M + 63) / 64), (Cin + 63) / 64, 1), dim3(256), 0, st, f,
+                           M, Cin, (int64_t)4 * Cout, 1);
     });
-    UH_CHECK_LAUNCH("convt2x2_dgrad_kernel");
+    UH_CHECK_LAUNCH("convt2x2_dgrad");
     return UH_OK;
 }
 
-static int convt_nsplit(int B, int h, int w_, int Cin) {
+static int convt_nsplit(int B, int h, int w_, int Cin, int Cout) {
     int64_t npix = (int64_t)B * h * w_;
-    int want = (2048 + Cin * 4 - 1) / (Cin * 4);
+    int tiles = ((Cin + 63) / 64) * ((4 * Cout + 63) / 64);
+    int want = (1024 + tiles - 1) / tiles;
     if (want < 1) want = 1;
-    if (want > npix) want = (int)npix;
-    if (want > 64) want = 64;
+    if (want > (npix + 63) / 64) want = (int)((npix + 63) / 64);
+    if (want > 128) want = 128;
     return want;
 }
 
 extern "C" size_t uh_convt2x2_wgrad_ws_bytes(int B, int h, int w_, int Cin, int Cout) {
-    return (size_t)convt_nsplit(B, h, w_, Cin) * ((size_t)Cin * Cout * 4 + Cout) * sizeof(float) + 16;
+    return (size_t)convt_nsplit(B, h, w_, Cin, Cout) * ((size_t)Cin * Cout * 4) * sizeof(float) + 16;
 }
 
 extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, float* dbias, void* ws,
@@ -152,22 +217,29 @@ extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ld
                                  int pad_left, int dt, uh_stream stream) {
     UH_REQUIRE(dy && x && dw && dbias && ws && B > 0 && h > 0 && w_ > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && ldx >= Cin,
                "uh_convt2x2_wgrad: bad args");
-    int nsplit = convt_nsplit(B, h, w_, Cin);
-    size_t need = (size_t)nsplit * ((size_t)Cin * Cout * 4 + Cout) * sizeof(float);
+    int nsplit = convt_nsplit(B, h, w_, Cin, Cout);
+    size_t need = (size_t)nsplit * ((size_t)Cin * Cout * 4) * sizeof(float);
     if (ws_bytes < need) {
         uh_set_error("uh_convt2x2_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
         return UH_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, need, st);   // bias slots are accumulated with atomics
+    CtGeom g = ct_geom(B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
+    const int64_t K = (int64_t)B * h * w_;
     UH_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL(convt2x2_wgrad_kernel<T>, dim3(Cin * 4, nsplit), dim3(256), 0, st, (const T*)dy, lddy,
-                           (const T*)x, ldx, (float*)ws, B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left, nsplit);
+        CtWgrad<T> f{(const T*)x, ldx, (const T*)dy, lddy, (float*)ws, g};
+        hipLaunchKernelGGL(ct_gemm_kernel<CtWgrad<T>>, dim3((Cin + 63) / 64, (4 * Cout + 63) / 64, nsplit), dim3(256), 0, st, f,
+                           (int64_t)Cin, 4 * Cout, K, nsplit);
+        hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+        int slices = (int)((K * 4 + 1023) / 1024);
+        if (slices > 512) slices = 512;
+        if (slices < 1) slices = 1;
+        hipLaunchKernelGGL(ct_dbias_kernel<T>, dim3((Cout + 63) / 64, slices), dim3(256), 0, st, (const T*)dy, lddy, g, dbias);
     });
-    UH_CHECK_LAUNCH("convt2x2_wgrad_kernel");
+    UH_CHECK_LAUNCH("convt2x2_wgrad");
     int64_t nw = (int64_t)Cin * Cout * 4;
-    hipLaunchKernelGGL(convt_slab_reduce_kernel, dim3((unsigned)((nw + Cout + 255) / 256)), dim3(256), 0, st,
-                       (const float*)ws, dw, dbias, nw, Cout, nsplit);
+    hipLaunchKernelGGL(convt_slab_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, nw,
+                       nsplit);
     UH_CHECK_LAUNCH("convt_slab_reduce_kernel");
     return UH_OK;
 }

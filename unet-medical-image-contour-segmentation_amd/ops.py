@@ -187,9 +187,10 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
 
 
 def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.dtype, iters: int = 20):
-    """Time the conv kernels of one DoubleConv(Cin -> Cout -> Cout) in isolation (HIP events on the launch
-    stream, `iters` back-to-back launches each).  Returns TFLOP/s per kernel; used by bench.py for the layer
-    the north-star's MFMA target is quoted on (the 256-channel DoubleConv)."""
+    """Time the conv kernels of one DoubleConv(Cin -> Cout -> Cout) in isolation: preallocated buffers, the C ABI
+    called back to back (`iters` launches between two HIP events on the launch stream, so the figure is kernel
+    time, not Python time).  Returns ms and TFLOP/s per kernel; bench.py reports it for the layer the north-star's
+    MFMA target is quoted on (the 256-channel DoubleConv)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(B, H, W, Cin, generator=g).to(dev, dtype)
@@ -198,7 +199,24 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
     w2 = (torch.randn(Cout, Cout, 3, 3, generator=g) / (3 * Cout ** 0.5)).to(dev)
     w1f, w1d = pack_w3x3(w1, dtype, True)
     w2f, w2d = pack_w3x3(w2, dtype, True)
+    dt = _dt(x)
+    yo = torch.empty(B, H, W, Cout, dtype=dtype, device=dev)
+    xo = torch.empty(B, H, W, Cin, dtype=dtype, device=dev)
+    nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cin, Cout, dt)
+    stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=dev)
     dw = torch.empty(Cout * 9 * Cout, dtype=torch.float32, device=dev)
+    wsb = max(LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cout, Cout, dt),
+              LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout, dt))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = _stream()
+
+    def fwd(src, cin, wp, dst, cout, stat):
+        LIB.call("uh_conv3x3_fwd", src.data_ptr(), cin, cin, None, 0, 0, wp.data_ptr(), dst.data_ptr(), cout, cout,
+                 _p(stat), B, H, W, dt, st)
+
+    def wgrad(dy, src, cin):
+        LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), Cout, src.data_ptr(), cin, cin, None, 0, 0, dw.data_ptr(), Cout,
+                 ws.data_ptr(), wsb, B, H, W, dt, st)
 
     def timeit(fn, flops):
         fn()
@@ -216,12 +234,12 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
     f2 = 2.0 * B * H * W * Cout * 9 * Cout
     out = {
         "shape": f"B{B} {H}x{W} {Cin}->{Cout}->{Cout} {str(dtype)[6:]}",
-        "fwd_conv1": timeit(lambda: conv3x3_fwd(x, None, w1f, Cout, True), f1),
-        "fwd_conv2": timeit(lambda: conv3x3_fwd(h, None, w2f, Cout, True), f2),
-        "dgrad_conv2": timeit(lambda: conv3x3_fwd(h, None, w2d, Cout, False), f2),
-        "dgrad_conv1": timeit(lambda: conv3x3_fwd(h, None, w1d, Cin, False), f1),
-        "wgrad_conv2": timeit(lambda: conv3x3_wgrad(h, h, None, dw), f2),
-        "wgrad_conv1": timeit(lambda: conv3x3_wgrad(h, x, None, dw[:Cout * 9 * Cin]), f1),
+        "fwd_conv1": timeit(lambda: fwd(x, Cin, w1f, yo, Cout, stats), f1),
+        "fwd_conv2": timeit(lambda: fwd(h, Cout, w2f, yo, Cout, stats), f2),
+        "dgrad_conv2": timeit(lambda: fwd(h, Cout, w2d, yo, Cout, None), f2),
+        "dgrad_conv1": timeit(lambda: fwd(h, Cout, w1d, xo, Cin, None), f1),
+        "wgrad_conv2": timeit(lambda: wgrad(h, h, Cout), f2),
+        "wgrad_conv1": timeit(lambda: wgrad(h, x, Cin), f1),
     }
     tot_f = 3 * f2 + 3 * f1
     tot_ms = sum(v["ms"] for k, v in out.items() if isinstance(v, dict))
