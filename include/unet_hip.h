@@ -189,6 +189,13 @@ int uh_seg_loss_binary_finish(const float* sums, double n_mean, const float* bou
 int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double n_mean, const float* boundary,
                                   float w_boundary, float* out, uh_stream stream);
 
+/* ---- connected_component_loss, host part  (utils/connected_component_loss.py:20-59) -----------
+ * masks: HOST uint8 [B][H][W], non-zero = (p > 0.5).  Restates cv2.findContours(RETR_EXTERNAL,
+ * CHAIN_APPROX_SIMPLE) + cv2.contourArea + cv2.boundingRect (Suzuki-Abe outer borders, shoelace area).
+ * out[0] = (sum of small-area and near-edge penalties) / B, out[1] = number of external contours.
+ * PARITY UNPINNED (OpenCV is not available in this image). */
+int uh_cc_loss_host(const uint8_t* masks, int B, int H, int W, int edge_distance, int min_area, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,5 +3,6 @@ nn.Module / loss-function surface).  See DESIGN.md and include/unet_hip.h."""
 from .unet import UNet, UNet_S, UNet_T, UNetDepth, DoubleConv, Down, Up, OutConv  # noqa: F401
 from .utils.dice_score import dice_coeff, multiclass_dice_coeff, dice_loss  # noqa: F401
 from .utils.boundary_loss import boundary_loss  # noqa: F401
+from .utils.connected_component_loss import connected_component_loss  # noqa: F401
 from .train import FusedRMSprop, seg_loss, train_step, TrainStepper  # noqa: F401
 from .evaluate import evaluate  # noqa: F401
