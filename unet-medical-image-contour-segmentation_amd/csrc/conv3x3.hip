@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
 constexpr int HALO2_BYTES = HALO_PIX * 64;   // 20736
 constexpr unsigned OOB_OFFSET = 0xF0000000u;
 
-// XOR applied to the 16-byte part index of halo pixel q: with part' = part ^ (2 * ((q >> 2) & 1)) the 16 lanes of
+// XOR applied to the 16-byte part index of a halo pixel in column hx: with part' = part ^ (2 * ((hx >> 2) & 1)) the 16 lanes of
 // every ds_read_b128 lane group (8 lanes of part k, 8 of part k^1, 16 consecutive pixels at ANY start) hit 16
 // distinct 16-byte slots of the 256-byte bank row -> conflict-free fragment reads for all nine taps.
-__device__ __forceinline__ int halo_swz(int q) { return ((q >> 2) & 1) << 1; }
+__device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }   // hx = halo COLUMN (0..17)
 
 template <typename T, int NBW>
 __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
     for (int k = 0; k < NLOAD; ++k) {
         int p = tid + k * 256;
-        src_part[k] = ((p & 3) ^ halo_swz(p >> 2)) * 16;
+        src_part[k] = ((p & 3) ^ halo_swz((p >> 2) % HALO_W)) * 16;
     }
     auto tile_pixels = [&](int tile, int (&pix)[NLOAD]) {
         int t = tile;
@@ -435,10 +435,9 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 __builtin_amdgcn_sched_barrier(0);
                 // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
                 u32x4 xf[18];
-                auto rd = [&](int k) {
-                    const int q = k * HALO_W + lx + s;
-                    return *reinterpret_cast<const u32x4*>(buf + q * 64 + ((kg ^ halo_swz(q)) << 4));
-                };
+                // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
+                const unsigned char* xcol = buf + (lx + s) * 64 + ((kg ^ halo_swz(lx + s)) << 4);
+                auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
                 xf[0] = rd(0);
                 xf[1] = rd(1);
                 xf[2] = rd(2);
@@ -1149,8 +1148,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int p = tid + k * 256;
-        const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+        const int q = p >> 3;
         const int hy = q / HALO_W, hx = q - hy * HALO_W;
+        const int u = (p & 7) ^ (((hx >> 1) & 1) << 2);          // swizzle by halo COLUMN: row independent
         xg[k] = (p < XUNITS) ? ((hy << 8) | hx) : -1;
         xo[k] = (hy * W + hx) * ldx * 2 + u * 16;
     }
@@ -1193,7 +1193,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-    auto lds_addr = [&](int q, int byte) -> int { return q * PB + (byte ^ (((q >> 1) & 1) << 6)); };
     const int l16 = lane & 15;
     const int grp = (lane >> 4) & 1;
     const int kh = lane >> 5;
@@ -1201,6 +1200,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     const int a_cbyte = (wr * 32 + grp * 16 + cp * 4) * 2;
     const int b_cbyte = (wc * 32 + grp * 16 + cp * 4) * 2;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
+    // Lane-constant LDS byte offsets of the two transposed reads of a fragment (pixels c, c+4 of a row); the halves
+    // of a 128-byte pixel row are swapped by ((column >> 1) & 1), so 4 consecutive pixels hit 4 distinct bank groups.
+    auto col_off = [&](int col, int cbyte) -> int { return col * PB + (cbyte ^ (((col >> 1) & 1) << 6)); };
+    const int d_lo = col_off(kh * 8 + rq, a_cbyte), d_hi = col_off(kh * 8 + rq + 4, a_cbyte);
+    int x_lo[3], x_hi[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        x_lo[s] = col_off(s + kh * 8 + rq, b_cbyte);
+        x_hi[s] = col_off(s + kh * 8 + rq + 4, b_cbyte);
+    }
 
     if (t_begin < t_end) issue(t_begin, 0);
     __syncthreads();
@@ -1209,39 +1218,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
-        // fragments of halo row hy+1 are fetched (transposed LDS reads) while row hy is multiplied
-        auto tr_pair = [&](const unsigned char* base, int q, int cbyte) -> bf16x8 {
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lds_addr(q, cbyte)));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lds_addr(q + 4, cbyte)));
-            s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
+            s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + lo));
+            s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + hi));
+            s16x8 both = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             return __builtin_bit_cast(bf16x8, both);
         };
         const bf16x8 zero8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        bf16x8 dfrag[3] = {zero8, zero8, zero8};
-        bf16x8 dcur = tr_pair(ds, kh * 8 + rq, a_cbyte), dnxt = zero8;
-        bf16x8 xcur[3], xnxt[3];
+        // fully unrolled over the 10 halo rows: row addresses are immediates, the dy fragments rotate by renaming,
+        // and the fragments of row hy+1 are fetched while row hy is multiplied
+        bf16x8 dfr[TH + 2];
+        bf16x8 xfr[TH + 2][3];
+        dfr[0] = tr_pair(ds, d_lo, d_hi);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) xcur[s] = tr_pair(xs, s + kh * 8 + rq, b_cbyte);
-#pragma unroll 1
+        for (int s = 0; s < 3; ++s) xfr[0][s] = tr_pair(xs, x_lo[s], x_hi[s]);
+#pragma unroll
         for (int hy = 0; hy < TH + 2; ++hy) {
             if (hy + 1 < TH + 2) {
-                dnxt = (hy + 1 < TH) ? tr_pair(ds, (hy + 1) * TILE + kh * 8 + rq, a_cbyte) : zero8;
+                dfr[hy + 1] = (hy + 1 < TH) ? tr_pair(ds + (hy + 1) * (TILE * PB), d_lo, d_hi) : zero8;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) xnxt[s] = tr_pair(xs, (hy + 1) * HALO_W + s + kh * 8 + rq, b_cbyte);
+                for (int s = 0; s < 3; ++s) xfr[hy + 1][s] = tr_pair(xs + (hy + 1) * (HALO_W * PB), x_lo[s], x_hi[s]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            dfrag[2] = dfrag[1];
-            dfrag[1] = dfrag[0];
-            dfrag[0] = dcur;
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
                     if (hy - r >= 0 && hy - r < TH)
-                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag[r], xcur[s], acc[r * 3 + s], 0, 0, 0);
-            dcur = dnxt;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) xcur[s] = xnxt[s];
+                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
         __syncthreads();    // drains the DMA of tile+1 (vmcnt(0)) and frees this buffer
     }
