@@ -130,19 +130,31 @@ extern "C" int uh_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 
 // ------------------------------------------------------------------------------------ apply
-template <typename T, int V>
+// HOIST: (gridDim.x * 256) % (C / V) == 0, so a thread keeps the same channel group on every grid-stride step and
+// its per-channel coefficients live in registers (otherwise they are re-read from L1 per element).
+template <typename T, int V, bool HOIST>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, T* __restrict__ z, int ldz,
                                                             int64_t npix, int C) {
     const int G = C / V;
     const int64_t total = npix * G;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sc[V], sh[V];
+    if constexpr (HOIST) {
+        const int c = (int)(first % G) * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+    }
+    for (int64_t idx = first; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int64_t p = idx / G;
         int c = (int)(idx - p * G) * V;
         float v[V];
         uh_load<T, V>(y + p * ldy + c, v);
 #pragma unroll
-        for (int i = 0; i < V; ++i) v[i] = fmaxf(fmaf(v[i], scale[c + i], shift[c + i]), 0.f);
+        for (int i = 0; i < V; ++i) {
+            if constexpr (HOIST) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+            else v[i] = fmaxf(fmaf(v[i], scale[c + i], shift[c + i]), 0.f);
+        }
         uh_store<T, V>(z + p * ldz + c, v);
     }
 }
@@ -160,22 +172,29 @@ extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, cons
     hipStream_t st = (hipStream_t)stream;
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(z, ldz, C))
-            hipLaunchKernelGGL((bn_relu_apply_kernel<T, VEC>), dim3(grid_for(npix * (C / VEC))), dim3(256), 0, st,
-                               (const T*)y, ldy, scale, shift, (T*)z, ldz, npix, C);
-        else
-            hipLaunchKernelGGL((bn_relu_apply_kernel<T, 1>), dim3(grid_for(npix * C)), dim3(256), 0, st, (const T*)y, ldy,
-                               scale, shift, (T*)z, ldz, npix, C);
+        if (uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(z, ldz, C)) {
+            const unsigned g = grid_for(npix * (C / VEC));
+            if (((int64_t)g * 256) % (C / VEC) == 0)
+                hipLaunchKernelGGL((bn_relu_apply_kernel<T, VEC, true>), dim3(g), dim3(256), 0, st, (const T*)y, ldy, scale,
+                                   shift, (T*)z, ldz, npix, C);
+            else
+                hipLaunchKernelGGL((bn_relu_apply_kernel<T, VEC, false>), dim3(g), dim3(256), 0, st, (const T*)y, ldy, scale,
+                                   shift, (T*)z, ldz, npix, C);
+        } else {
+            hipLaunchKernelGGL((bn_relu_apply_kernel<T, 1, false>), dim3(grid_for(npix * C)), dim3(256), 0, st, (const T*)y,
+                               ldy, scale, shift, (T*)z, ldz, npix, C);
+        }
     });
     UH_CHECK_LAUNCH("bn_relu_apply_kernel");
     return UH_OK;
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Thread = (pixel lane, channel group of V).  Block covers a contiguous pixel range.
+// Thread = (pixel lane, channel group of V).  Block = a contiguous pixel range (blockIdx.x) x a slab of up to
+// 8 channel groups (blockIdx.y), so small feature maps with many channels still fill the chip.
 extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
     (void)C;
-    int64_t n = (npix + 511) / 512;
+    int64_t n = (npix + 255) / 256;
     if (n > 512) n = 512;
     if (n < 1) n = 1;
     return (int)n;
@@ -188,52 +207,50 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd,
                                                                  float* __restrict__ partials, int64_t npix, int C) {
-    extern __shared__ float red[];   // [PL][2][GB*V]
-    const int G = C / V;                              // channel groups
-    const int GB = G < 256 ? G : 256;                 // groups handled per pass
-    const int PL = 256 / GB;                          // pixel lanes
+    constexpr int GB = 8;                             // channel groups per block
+    constexpr int PL = 256 / GB;                      // 32 pixel lanes
+    __shared__ float red[PL][2][GB * V];
+    const int G = C / V;
     const int g_in = threadIdx.x % GB, pl = threadIdx.x / GB;
+    const int g = blockIdx.y * GB + g_in;
+    const bool act = g < G;
+    const int c = g * V;
     const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per;
     const int64_t p1 = (p0 + per < npix) ? p0 + per : npix;
-    for (int gb = 0; gb < G; gb += GB) {
-        const int g = gb + g_in;
-        const bool act = (pl < PL) && (g < G);
-        const int c = g * V;
-        float s1[V], s2[V], sc[V], sh[V], mu[V], rs[V];
+    float s1[V], s2[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        if (act) {
+    for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    if (act) {
+        float sc[V], sh[V], mu[V], rs[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; }
-            for (int64_t p = p0 + pl; p < p1; p += PL) {
-                float d[V], yv[V];
-                uh_load<T, V>(dz + p * lddz + c, d);
-                uh_load<T, V>(y + p * ldy + c, yv);
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    float m = (fmaf(yv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
-                    s1[i] += m;
-                    s2[i] += m * (yv[i] - mu[i]) * rs[i];
-                }
-            }
-        }
-        __syncthreads();
-        if (act) {
+        for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; }
+        for (int64_t p = p0 + pl; p < p1; p += PL) {
+            float d[V], yv[V];
+            uh_load<T, V>(dz + p * lddz + c, d);
+            uh_load<T, V>(y + p * ldy + c, yv);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                red[(pl * 2 + 0) * (GB * V) + g_in * V + i] = s1[i];
-                red[(pl * 2 + 1) * (GB * V) + g_in * V + i] = s2[i];
+                float m = (fmaf(yv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
+                s1[i] += m;
+                s2[i] += m * (yv[i] - mu[i]) * rs[i];
             }
         }
-        __syncthreads();
-        for (int k = threadIdx.x; k < 2 * GB * V; k += 256) {
-            int which = k / (GB * V), cc = k - which * (GB * V);
-            if (gb * V + cc < C) {
-                float v = 0.f;
-                for (int q = 0; q < PL; ++q) v += red[(q * 2 + which) * (GB * V) + cc];
-                partials[((int64_t)blockIdx.x * 2 + which) * C + gb * V + cc] = v;
-            }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        red[pl][0][g_in * V + i] = s1[i];
+        red[pl][1][g_in * V + i] = s2[i];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * GB * V; k += 256) {
+        const int which = k / (GB * V), cc = k - which * (GB * V);
+        const int ch = blockIdx.y * GB * V + cc;
+        if (ch < C) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < PL; ++q) v += red[q][which][cc];
+            partials[((int64_t)blockIdx.x * 2 + which) * C + ch] = v;
         }
     }
 }
@@ -248,14 +265,11 @@ extern "C" int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, in
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
         if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C)) {
-            int G = C / VEC, GB = G < 256 ? G : 256, PL = 256 / GB;
-            size_t sm = (size_t)PL * 2 * GB * VEC * sizeof(float);
-            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, VEC>), dim3(nblk), dim3(256), sm, st, (const T*)dz, lddz,
-                               (const T*)y, ldy, scale, shift, mean, rstd, partials, npix, C);
+            int G = C / VEC;
+            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, VEC>), dim3(nblk, (G + 7) / 8), dim3(256), 0, st, (const T*)dz,
+                               lddz, (const T*)y, ldy, scale, shift, mean, rstd, partials, npix, C);
         } else {
-            int G = C, GB = G < 256 ? G : 256, PL = 256 / GB;
-            size_t sm = (size_t)PL * 2 * GB * sizeof(float);
-            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, 1>), dim3(nblk), dim3(256), sm, st, (const T*)dz, lddz,
+            hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<T, 1>), dim3(nblk, (C + 7) / 8), dim3(256), 0, st, (const T*)dz, lddz,
                                (const T*)y, ldy, scale, shift, mean, rstd, partials, npix, C);
         }
     });
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
-template <typename T, int V>
+template <typename T, int V, bool HOIST>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                                 int ldy, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift,
@@ -296,18 +310,31 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
                                                                 int lddy, int64_t npix, int C, float inv_n) {
     const int G = C / V;
     const int64_t total = npix * G;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // dy = [z>0]*a*dz + b*y + k  with a = scale, b = -scale*rstd*dgamma/n, k = -scale*dbeta/n - b*mean
+    float ca[V], cs[V], cb[V], ck[V];
+    auto coeffs = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float sc = scale[c + i];
+            ca[i] = sc;
+            cs[i] = shift[c + i];
+            cb[i] = -sc * rstd[c + i] * dgamma[c + i] * inv_n;
+            ck[i] = -sc * dbeta[c + i] * inv_n - cb[i] * mean[c + i];
+        }
+    };
+    if constexpr (HOIST) coeffs((int)(first % G) * V);
+    for (int64_t idx = first; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int64_t p = idx / G;
         int c = (int)(idx - p * G) * V;
+        if constexpr (!HOIST) coeffs(c);
         float d[V], yv[V], o[V];
         uh_load<T, V>(dz + p * lddz + c, d);
         uh_load<T, V>(y + p * ldy + c, yv);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float sc = scale[c + i];
-            float m = (fmaf(yv[i], sc, shift[c + i]) > 0.f) ? d[i] : 0.f;
-            float xh = (yv[i] - mean[c + i]) * rstd[c + i];
-            o[i] = sc * (m - dbeta[c + i] * inv_n - xh * dgamma[c + i] * inv_n);
+            const float m = (fmaf(yv[i], ca[i], cs[i]) > 0.f) ? d[i] : 0.f;
+            o[i] = fmaf(ca[i], m, fmaf(cb[i], yv[i], ck[i]));
         }
         uh_store<T, V>(dy + p * lddy + c, o);
     }
@@ -326,14 +353,21 @@ extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int
     float inv_n = (float)(1.0 / (double)npix);
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(dy, lddy, C))
-            hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, VEC>), dim3(grid_for(npix * (C / VEC))), dim3(256), 0, st,
+        if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(dy, lddy, C)) {
+            const unsigned g = grid_for(npix * (C / VEC));
+            if (((int64_t)g * 256) % (C / VEC) == 0)
+                hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, VEC, true>), dim3(g), dim3(256), 0, st, (const T*)dz, lddz,
+                                   (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma, (const float*)dbeta,
+                                   (T*)dy, lddy, npix, C, inv_n);
+            else
+                hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, VEC, false>), dim3(g), dim3(256), 0, st, (const T*)dz, lddz,
+                                   (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma, (const float*)dbeta,
+                                   (T*)dy, lddy, npix, C, inv_n);
+        } else {
+            hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, 1, false>), dim3(grid_for(npix * C)), dim3(256), 0, st,
                                (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma,
                                (const float*)dbeta, (T*)dy, lddy, npix, C, inv_n);
-        else
-            hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<T, 1>), dim3(grid_for(npix * C)), dim3(256), 0, st, (const T*)dz,
-                               lddz, (const T*)y, ldy, scale, shift, mean, rstd, (const float*)dgamma,
-                               (const float*)dbeta, (T*)dy, lddy, npix, C, inv_n);
+        }
     });
     UH_CHECK_LAUNCH("bn_relu_bwd_apply_kernel");
     return UH_OK;

@@ -201,20 +201,43 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
         int ylo, yhi, xlo, xhi;
         up_range(iy, sy, h, ylo, yhi);
         up_range(ix, sx, w, xlo, xhi);
+        // the column weights do not depend on the row: evaluate them once (at most MAXC candidates by construction
+        // of up_range for a x2 upsample; wider ranges -- only when scale == 0 -- fall back to on-the-fly weights)
+        constexpr int MAXC = 8;
+        float wxs[MAXC];
+        const bool cached = (xhi - xlo) < MAXC;
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) wxs[k] = (xlo + k <= xhi) ? up_weight(xlo + k, sx, w, ix) : 0.f;
+        }
         for (int uy = ylo; uy <= yhi; ++uy) {
             float wy = up_weight(uy, sy, h, iy);
             int oy = uy + pt;
             if (wy == 0.f || oy < 0 || oy >= Ho) continue;
-            for (int ux = xlo; ux <= xhi; ++ux) {
-                float wx = up_weight(ux, sx, w, ix);
-                int ox = ux + pl;
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                const int ux = xlo + k;
+                if (!cached || ux > xhi) break;
+                const float wx = wxs[k];
+                const int ox = ux + pl;
                 if (wx == 0.f || ox < 0 || ox >= Wo) continue;
                 float g[V];
                 uh_load<T, V>(dy + ((int64_t)(b * Ho + oy) * Wo + ox) * lddy + c, g);
-                float ww = wy * wx;
+                const float ww = wy * wx;
 #pragma unroll
                 for (int i = 0; i < V; ++i) acc[i] = fmaf(ww, g[i], acc[i]);
             }
+            if (!cached)
+                for (int ux = xlo; ux <= xhi; ++ux) {
+                    float wx = up_weight(ux, sx, w, ix);
+                    int ox = ux + pl;
+                    if (wx == 0.f || ox < 0 || ox >= Wo) continue;
+                    float g[V];
+                    uh_load<T, V>(dy + ((int64_t)(b * Ho + oy) * Wo + ox) * lddy + c, g);
+                    float ww = wy * wx;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] = fmaf(ww, g[i], acc[i]);
+                }
         }
         uh_store<T, V>(dx + p * lddx + c, acc);
     }
