@@ -72,6 +72,10 @@ class BucketedGradSync:
             return
         s, e = self.buckets[b]
         view = self.flat[s:e]
+        if self.flat.is_cuda:
+            from . import ops
+            if ops.WGRAD_STREAM is not None:      # weight gradients of this bucket may still be in flight there
+                torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
         h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.handles.append((h, view))

@@ -124,6 +124,11 @@ def _empty_like_param(p: torch.Tensor) -> torch.Tensor:
     return torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=p.device)
 
 
+# Optional second HIP stream for backward-weights (set by TrainStepper): wgrad only feeds the optimizer, so it can run
+# beside the backward-data conv and the HBM-bound BatchNorm-backward kernels of the layers that follow.
+WGRAD_STREAM = None
+
+
 # FusedRMSprop registers, per parameter storage, the view of its flat gradient buffer that the backward kernels
 # should write into directly (no gather copy afterwards).  Keyed by data_ptr of the parameter.
 GRAD_DST = {}
@@ -320,7 +325,17 @@ class ConvBnReluFn(Function):
         dweight = None
         if ctx.needs_input_grad[2]:
             dweight, cb_w = _grad_buffer(weight)
-            if _is_krsc_dense(weight):
+            if cb_w is not None and WGRAD_STREAM is not None and _is_krsc_dense(weight):
+                side = WGRAD_STREAM
+                ev = torch.cuda.Event()
+                ev.record()                         # dy is complete on the main stream at this point
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    conv3x3_wgrad(dy, x0, x1, dweight)
+                for t_ in (dy, x0, x1):
+                    if t_ is not None:
+                        t_.record_stream(side)      # the caching allocator must not recycle them under the side stream
+            elif _is_krsc_dense(weight):
                 conv3x3_wgrad(dy, x0, x1, dweight)
             else:
                 dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)

@@ -119,6 +119,8 @@ class FusedRMSprop:
 
     @torch.no_grad()
     def step(self):
+        if ops.WGRAD_STREAM is not None:
+            torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)     # weight gradients written on the side stream
         if self.sync is not None:
             self.sync.wait()
         g = self.param_groups[0]
@@ -188,8 +190,11 @@ class TrainStepper:
     """Model + FusedRMSprop (+ RCCL gradient sync when torch.distributed is initialised)."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
-                 gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True):
+                 gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
+                 wgrad_stream: bool = True):
         self.model = model
+        if wgrad_stream and ops.WGRAD_STREAM is None:
+            ops.WGRAD_STREAM = torch.cuda.Stream()
         self.amp = amp
         self.check_nan = check_nan
         self.group = process_group
