@@ -758,6 +758,118 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v2(const T* __restrict__
 }
 
 // =====================================================================================
+// forward, stem v3 (Cin <= 4, Cout == 64): persistent workgroups walk the 16x16 tiles; thread = (pixel lane of 32,
+// 8 consecutive output channels) so every store is a 16-byte piece of a full pixel row; the 9*Cin*8 filter taps
+// live in registers for the whole kernel; BatchNorm statistics are shifted sums (shift K = the workgroup's first
+// output pixel) accumulated in registers over ALL tiles of the workgroup and reduced once: one slab per workgroup.
+// =====================================================================================
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__ x, int ldx, const T* __restrict__ w,
+                                                           T* __restrict__ y, int ldy, float* __restrict__ stats, int B,
+                                                           int H, int W, int tilesX, int tilesY) {
+    constexpr int V = 8, COUT = 64;
+    __shared__ float xs[HALO_PIX * CIN];
+    __shared__ float kshift[COUT];
+    __shared__ float red[4][2][COUT];
+    const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;      // 8 channel groups x 32 pixel lanes
+    const int ntile = B * tilesX * tilesY;
+    float wr[9 * CIN][V];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) wr[k][i] = uh_to_f32(w[((int64_t)(g * V + i) * 9 + k / CIN) * CIN + (k % CIN)]);
+    float s1[V], s2[V], ks[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; ks[i] = 0.f; }
+    float cnt = 0.f;
+    bool have_k = false;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int t = tile;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TILE, x0p = txt * TILE;
+        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        __syncthreads();
+        for (int idx = tid; idx < HALO_PIX * CIN; idx += 256) {
+            int q = idx / CIN, ci = idx - q * CIN;
+            int hy = q / HALO_W, hx = q - hy * HALO_W;
+            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
+            xs[idx] = v;
+        }
+        __syncthreads();
+        float out[8][V];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = pl + j * 32, ty = px >> 4, tx = px & 15;
+            float a[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) a[i] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int ss = 0; ss < 3; ++ss)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const float xv = xs[((ty + r) * HALO_W + tx + ss) * CIN + ci];
+#pragma unroll
+                        for (int i = 0; i < V; ++i) a[i] = fmaf(xv, wr[(r * 3 + ss) * CIN + ci][i], a[i]);
+                    }
+#pragma unroll
+            for (int i = 0; i < V; ++i) out[j][i] = uh_round_as<T>(a[i]);
+            if (ty < vy && tx < vx) uh_store<T, V>(y + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + g * V, out[j]);
+        }
+        if (stats) {
+            if (!have_k) {                   // shift = this workgroup's first output pixel (valid: tile origin is in range)
+                if (pl == 0) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) kshift[g * V + i] = out[0][i];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < V; ++i) ks[i] = kshift[g * V + i];
+                have_k = true;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = pl + j * 32;
+                if ((px >> 4) < vy && (px & 15) < vx) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) { const float d = out[j][i] - ks[i]; s1[i] += d; s2[i] += d * d; }
+                }
+            }
+            cnt += (float)(vy * vx);
+        }
+    }
+    if (stats) {
+        // reduce over the 32 pixel lanes: lanes of a wave with equal g differ in bits 3..5; then across the 4 waves
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            for (int o = 8; o < 64; o <<= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+        __syncthreads();
+        if ((tid & 63) < 8) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { red[tid >> 6][0][g * V + i] = s1[i]; red[tid >> 6][1][g * V + i] = s2[i]; }
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            const float a = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+            const float q = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            const float n = cnt > 0.f ? cnt : 1.f;
+            const float kk = have_k ? kshift[tid] : 0.f;
+            stats[((int64_t)blockIdx.x * 2 + 0) * COUT + tid] = kk + a / n;                   // mean
+            stats[((int64_t)blockIdx.x * 2 + 1) * COUT + tid] = fmaxf(q - a * a / n, 0.f);     // M2 (shifted-data formula)
+        }
+        // slab layout is sized for one row per TILE: rows beyond the workgroup count get a zero pixel count (skipped)
+        float* counts = stats + (int64_t)ntile * 2 * COUT;
+        if (tid == 0) counts[blockIdx.x] = cnt;
+        for (int r = gridDim.x + blockIdx.x * 256 + tid; r < ntile; r += gridDim.x * 256) counts[r] = 0.f;
+    }
+}
+
+// =====================================================================================
 // forward, generic (any channel counts)
 // =====================================================================================
 template <typename T>
@@ -868,6 +980,19 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
     }
     if (Cin <= 4 && C1 == 0) {
         constexpr int V = 16 / ES;
+        if constexpr (ES == 2) {
+            if (Cout == 64 && uh_aligned16(y) && (ldy * ES) % 16 == 0) {
+                int grid = ntile < 1024 ? ntile : 1024;
+                switch (Cin) {
+                    case 1: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 1>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
+                    case 2: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 2>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
+                    case 3: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 3>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
+                    default: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 4>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
+                }
+                UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3");
+                return UH_OK;
+            }
+        }
         if (Cout % V == 0 && uh_aligned16(y) && (ldy * ES) % 16 == 0) {
             int G = Cout / V, GB = G < 8 ? G : 8, CG = GB * V;
             size_t sm = (size_t)(HALO_PIX * 4 + 36 * CG + CG) * sizeof(float);
@@ -1401,6 +1526,82 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v2(const T* __restrict
     }
 }
 
+// ---- stem wgrad v3 (Cin <= 4, Cout == 64): persistent workgroups over 16x16 tiles, x halo in LDS, thread = (pixel lane
+// of 32, 8 output channels) with 9*Cin*8 accumulators in registers; one slab per workgroup.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict__ dy, int lddy, const T* __restrict__ x,
+                                                             int ldx, float* __restrict__ slabs, int B, int H, int W,
+                                                             int tilesX, int tilesY) {
+    constexpr int V = 8, COUT = 64;
+    __shared__ float xs[HALO_PIX * CIN];
+    __shared__ float red[4][9 * CIN][COUT];
+    const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;
+    const int ntile = B * tilesX * tilesY;
+    float acc[9 * CIN][V];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int t = tile;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TILE, x0p = txt * TILE;
+        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        __syncthreads();
+        for (int idx = tid; idx < HALO_PIX * CIN; idx += 256) {
+            int q = idx / CIN, ci = idx - q * CIN;
+            int hy = q / HALO_W, hx = q - hy * HALO_W;
+            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
+            xs[idx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = pl + j * 32, ty = px >> 4, tx = px & 15;
+            if (ty < vy && tx < vx) {
+                float d[V];
+                uh_load<T, V>(dy + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * lddy + g * V, d);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int ss = 0; ss < 3; ++ss)
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) {
+                            const float xv = xs[((ty + r) * HALO_W + tx + ss) * CIN + ci];
+#pragma unroll
+                            for (int i = 0; i < V; ++i) acc[(r * 3 + ss) * CIN + ci][i] = fmaf(d[i], xv, acc[(r * 3 + ss) * CIN + ci][i]);
+                        }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float v = acc[k][i];
+            for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            acc[k][i] = v;
+        }
+    __syncthreads();
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) red[tid >> 6][k][g * V + i] = acc[k][i];
+    }
+    __syncthreads();
+    float* slab = slabs + (int64_t)blockIdx.x * COUT * 9 * CIN;
+    for (int idx = tid; idx < 9 * CIN * COUT; idx += 256) {
+        const int k = idx / COUT, c = idx - k * COUT;
+        // slab layout [co][tap][ci]
+        slab[((int64_t)c * 9 + k / CIN) * CIN + (k % CIN)] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    }
+}
+
 // ---- generic wgrad: one block per (co, tap); threads stride over ci; serial over pixels
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_generic(const T* __restrict__ dy, int lddy, const T* __restrict__ x0,
@@ -1518,7 +1719,17 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         }
     } else {
         constexpr int V = 16 / ES;
-        if (Cout % V == 0 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {
+        bool done = false;
+        if constexpr (ES == 2) {
+            if (Cin == 1 && Cout == 64 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {      // 72 accumulators per lane
+                hipLaunchKernelGGL((conv3x3_wgrad_stem_v3<T, 1>), dim3(p.nsplit), dim3(256), 0, st, dy, lddy, x0, ld0, slabs, B,
+                                   H, W, p.tilesX, p.tilesY);
+                UH_CHECK_LAUNCH("conv3x3_wgrad_stem_v3");
+                done = true;
+            }
+        }
+        if (done) {
+        } else if (Cout % V == 0 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {
             hipLaunchKernelGGL(conv3x3_wgrad_stem_v2<T>, dim3(p.nsplit, 1, Cin), dim3(256), 0, st, dy, lddy, x0, Cin, ld0,
                                slabs, Cout, B, H, W, p.nsplit);
             UH_CHECK_LAUNCH("conv3x3_wgrad_stem_v2");
