@@ -47,6 +47,8 @@ def cpu_baseline(size: int):
     reference's golden fixtures) timed on this host: BASELINE config 1 = batch 2, 1x512x512, fp32."""
     from oracle import step_ref as S
     from oracle import unet_ref as U
+    # the GPU box gives one GPU a share of 16 host cores (the machine shows 256): oversubscribing slows oneDNN down
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     torch.manual_seed(0)
     st = U.init_state(1, 1, True, seed=0)
     g = torch.Generator().manual_seed(1)
@@ -118,8 +120,10 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         ops.PROFILE.clear()
         ops.PROFILE_ON = True
+        side, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None      # time every kernel alone on the launch stream
         stepper.step(images, masks)
         torch.cuda.synchronize()
+        ops.WGRAD_STREAM = side
         ops.PROFILE_ON = False
         agg = {}
         for name, flops, e0, e1 in ops.PROFILE:
