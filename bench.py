@@ -136,8 +136,18 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         peak = MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS
         ach = dom[1][2] / dom[1][1] / 1e12
+        # HBM bytes per launch of this kernel family from the PMC passes committed under profiles/ (rocprofv3 cannot be
+        # driven from inside the process); null for configurations that were not profiled
+        traffic = None
+        try:
+            if amp and bilinear and B == 8 and S == 512:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
+                traffic = tj.get(dom[0] + "_per_launch", {}).get("hbm_MB")
+                traffic = None if traffic is None else round(traffic * 1e6)
+        except Exception:
+            traffic = None
         roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None,
+                "frac": round(ach / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
         # the layer the north-star names: the 256-channel DoubleConv (down2: 128->256->256 at 128x128, batch 8)
         kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)

@@ -337,7 +337,21 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lx = lane & 15, kg = lane >> 4;
-    const int co_blk = blockIdx.y * BN;
+    // XCD-aware block mapping (1-D grid of nlanes * nslab workgroups, nlanes % 8 == 0 or nslab == 1): blocks are dealt
+    // round-robin to the 8 XCDs, so id % 8 labels the XCD; all channel slabs of one tile lane get the SAME label and
+    // adjacent dispatch slots -> the slabs re-read the same input tile from that XCD's L2 instead of from HBM.
+    const int nslab = Cout / BN;
+    const int nlanes = gridDim.x / nslab;
+    int tile_lane, slab;
+    if ((nlanes & 7) == 0) {
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        slab = jj % nslab;
+        tile_lane = (jj / nslab) * 8 + xcd;
+    } else {
+        slab = blockIdx.x / nlanes;
+        tile_lane = blockIdx.x - slab * nlanes;
+    }
+    const int co_blk = slab * BN;
     const int co_w = co_blk + wave * (NBW * 16);
     const int Cin = C0 + C1;
     const int nchunk = Cin / CK;
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     // tile, so a workgroup never waits for a cold HBM round trip after its first tile (matters for the
     // HBM-bound 64-channel 512x512 layers, which have only 2 K-chunks per tile).
     int pix_cur[NLOAD], pix_nxt[NLOAD];
-    int tile = blockIdx.x;
+    int tile = tile_lane;
     if (tile >= ntile) return;
     tile_pixels(tile, pix_cur);
     dma_chunk(pix_cur, 0, 0);
@@ -405,8 +419,8 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     __syncthreads();     // drains the DMA (vmcnt(0)) before anyone reads buffer 0
     int bufi = 0;
 
-    for (; tile < ntile; tile += gridDim.x) {
-        const int next_tile = tile + gridDim.x;
+    for (; tile < ntile; tile += nlanes) {
+        const int next_tile = tile + nlanes;
         f32x4 acc[16][NBW];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                         stats[((int64_t)tile * 2 + 1) * Cout + ch] = a;
                     }
                 }
-            if (blockIdx.y == 0 && tid == 0) stats[(int64_t)ntile * 2 * Cout + tile] = (float)(vy * vx);
+            if (slab == 0 && tid == 0) stats[(int64_t)ntile * 2 * Cout + tile] = (float)(vy * vx);
         }
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) pix_cur[k] = pix_nxt[k];
@@ -953,16 +967,21 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         const int64_t b0 = (int64_t)B * H * W * ld0 * ES, b1 = C1 ? (int64_t)B * H * W * ld1 * ES : 0;
         if (b0 < (1ll << 31) - 4096 && b1 < (1ll << 31) - 4096) {
             // 128-channel slabs halve the halo re-reads, but small feature maps need the extra workgroups
-            // persistent workgroups: ~3 per CU (LDS 41.5 KB each) spread over the channel slabs
-            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
-                int slabs = Cout / 128, gx = (2 * 256 + slabs - 1) / slabs;       // NBW=2: 2 workgroups per CU by VGPRs
+            // persistent workgroups: 2 (NBW=2, VGPR-bound) or 3 (NBW=1) per CU, spread over the channel slabs; the
+            // number of tile lanes is rounded to a multiple of 8 for the XCD-aware mapping inside the kernel
+            auto lanes_for = [&](int per_cu, int slabs) {
+                int gx = (per_cu * 256 + slabs - 1) / slabs;
+                gx = (gx + 7) & ~7;
                 if (gx > ntile) gx = ntile;
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx, slabs), dim3(256), 0, st, x0, C0, ld0, x1,
+                return gx;
+            };
+            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
+                int slabs = Cout / 128, gx = lanes_for(2, slabs);
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                    C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
             } else {
-                int slabs = Cout / 64, gx = (3 * 256 + slabs - 1) / slabs;
-                if (gx > ntile) gx = ntile;
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx, slabs), dim3(256), 0, st, x0, C0, ld0, x1,
+                int slabs = Cout / 64, gx = lanes_for(3, slabs);
+                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                    C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
