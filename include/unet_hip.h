@@ -58,6 +58,12 @@ int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int dt);
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
                    int B, int H, int W, int dt, uh_stream stream);
+/* Inference form of (Conv2d -> BatchNorm2d(eval) -> ReLU)  (unet_parts.py:15-20 under model.eval(),
+ * evaluate.py:30 / predict.py:17): z = max(conv(x, w)*scale + shift, 0) with scale/shift from
+ * uh_bn_eval_coeffs, applied to the accumulators -- the pre-BatchNorm tensor is never written. */
+int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
+                               const void* w, void* z, int ldz, int Cout, const float* scale,
+                               const float* shift, int B, int H, int W, int dt, uh_stream stream);
 /* conv backward-weights: dw[o][r][s][i] = sum_{b,h,w} dy[b,h,w,o] * x[b,h+r-1,w+s-1,i] (fp32 KRSC). */
 size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
 int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
@@ -195,6 +201,12 @@ int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double n_mean, co
  * out[0] = (sum of small-area and near-edge penalties) / B, out[1] = number of external contours.
  * PARITY UNPINNED (OpenCV is not available in this image). */
 int uh_cc_loss_host(const uint8_t* masks, int B, int H, int W, int edge_distance, int min_area, double* out);
+
+/* ---- inference masks  (predict.py:27, evaluate.py:60-62,111) ------------------------------------
+ * uh_argmax_classes: logits fp32 [npix][ncls] -> int64 index of the first maximum per pixel (torch.argmax(dim=1)).
+ * uh_threshold_mask: binary head, out = (logit > 0) as 0.0/1.0  (== sigmoid(logit) > 0.5). */
+int uh_argmax_classes(const float* logits, int64_t npix, int ncls, int64_t* out, uh_stream stream);
+int uh_threshold_mask(const float* logits, int64_t n, float* out, uh_stream stream);
 
 #ifdef __cplusplus
 }

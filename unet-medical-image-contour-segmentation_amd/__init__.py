@@ -6,3 +6,5 @@ from .utils.boundary_loss import boundary_loss  # noqa: F401
 from .utils.connected_component_loss import connected_component_loss  # noqa: F401
 from .train import FusedRMSprop, seg_loss, train_step, TrainStepper  # noqa: F401
 from .evaluate import evaluate  # noqa: F401
+from .predict import predict_img, mask_to_image, preprocess_image  # noqa: F401
+from .checkpoint import save_checkpoint, load_checkpoint  # noqa: F401

@@ -323,7 +323,8 @@ template <typename T, int NBW>
 __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
-    int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes) {
+    int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes,
+    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift) {
     constexpr int ES = sizeof(T);
     constexpr int CK = 64 / ES;
     constexpr int VEC = 16 / ES;
@@ -494,6 +495,17 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         const int gx = x0p + lx;
         const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
         const float inv_cnt = 1.f / (float)(vy * vx);
+        if (ep_scale) {      // inference: eval-mode BatchNorm (per-channel scale/shift) + ReLU applied to the accumulators
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + co_w + n * 16 + kg * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + co_w + n * 16 + kg * 4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][n][j] = fmaxf(fmaf(acc[i][n][j], sc[j], sh[j]), 0.f);
+            }
+        }
         float ssum[NBW][4];
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
@@ -780,7 +792,9 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v2(const T* __restrict__
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__ x, int ldx, const T* __restrict__ w,
                                                            T* __restrict__ y, int ldy, float* __restrict__ stats, int B,
-                                                           int H, int W, int tilesX, int tilesY) {
+                                                           int H, int W, int tilesX, int tilesY,
+                                                           const float* __restrict__ ep_scale,
+                                                           const float* __restrict__ ep_shift) {
     constexpr int V = 8, COUT = 64;
     __shared__ float xs[HALO_PIX * CIN];
     __shared__ float kshift[COUT];
@@ -795,6 +809,9 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
     float s1[V], s2[V], ks[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; ks[i] = 0.f; }
+    float esc[V], esh[V];                 // inference epilogue: eval-mode BatchNorm scale/shift + ReLU
+#pragma unroll
+    for (int i = 0; i < V; ++i) { esc[i] = ep_scale ? ep_scale[g * V + i] : 1.f; esh[i] = ep_scale ? ep_shift[g * V + i] : 0.f; }
     float cnt = 0.f;
     bool have_k = false;
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -831,6 +848,10 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
 #pragma unroll
                         for (int i = 0; i < V; ++i) a[i] = fmaf(xv, wr[(r * 3 + ss) * CIN + ci][i], a[i]);
                     }
+            if (ep_scale) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) a[i] = fmaxf(fmaf(a[i], esc[i], esh[i]), 0.f);
+            }
 #pragma unroll
             for (int i = 0; i < V; ++i) out[j][i] = uh_round_as<T>(a[i]);
             if (ty < vy && tx < vx) uh_store<T, V>(y + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + g * V, out[j]);
@@ -954,7 +975,11 @@ extern "C" int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int
 
 template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
-                                int Cout, float* stats, int B, int H, int W, hipStream_t st) {
+                                int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
+                                const float* ep_shift, bool* ep_done) {
+    // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
+    // runs the separate scale/shift/ReLU pass
+    *ep_done = false;
     constexpr int ES = sizeof(T);
     constexpr int CK = 64 / ES;
     const int tilesX = (W + TILE - 1) / TILE, tilesY = (H + TILE - 1) / TILE;
@@ -975,16 +1000,18 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                 if (gx > ntile) gx = ntile;
                 return gx;
             };
+            if (ep_scale && !(uh_aligned16(ep_scale) && uh_aligned16(ep_shift))) ep_scale = ep_shift = nullptr;   // 16-B loads
             if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
                 hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
+                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
                 hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1);
+                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
+            *ep_done = ep_scale != nullptr;
             return UH_OK;
         }
         if (Cout % 128 == 0) {
@@ -1003,12 +1030,13 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             if (Cout == 64 && uh_aligned16(y) && (ldy * ES) % 16 == 0) {
                 int grid = ntile < 1024 ? ntile : 1024;
                 switch (Cin) {
-                    case 1: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 1>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
-                    case 2: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 2>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
-                    case 3: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 3>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
-                    default: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 4>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY); break;
+                    case 1: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 1>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY, ep_scale, ep_shift); break;
+                    case 2: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 2>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY, ep_scale, ep_shift); break;
+                    case 3: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 3>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY, ep_scale, ep_shift); break;
+                    default: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<T, 4>), dim3(grid), dim3(256), 0, st, x0, ld0, w, y, ldy, stats, B, H, W, tilesX, tilesY, ep_scale, ep_shift); break;
                 }
                 UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3");
+                *ep_done = ep_scale != nullptr;
                 return UH_OK;
             }
         }
@@ -1045,11 +1073,36 @@ extern "C" int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, i
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd: pixel count overflows int32");
     UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_conv3x3_fwd: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
+    bool done;
     if (dt == UH_BF16)
         return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w,
-                                            (bf16_t*)y, ldy, Cout, stat_partials, B, H, W, st);
+                                            (bf16_t*)y, ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done);
     return conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)y,
-                                       ldy, Cout, stat_partials, B, H, W, st);
+                                       ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done);
+}
+
+// Inference forward: z = max(conv(x, w) * scale + shift, 0) with the eval-mode BatchNorm coefficients of
+// uh_bn_eval_coeffs.  The MFMA and stem kernels apply them to the accumulators (no intermediate tensor, one
+// rounding); the fallback kernels are followed by the in-place uh_bn_relu_apply pass.
+extern "C" int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1, const void* w,
+                                          void* z, int ldz, int Cout, const float* scale, const float* shift, int B,
+                                          int H, int W, int dt, uh_stream stream) {
+    UH_REQUIRE(x0 && w && z && scale && shift, "uh_conv3x3_fwd_affine_relu: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd_affine_relu: bad shape");
+    UH_REQUIRE(ld0 >= C0 && ldz >= Cout && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_fwd_affine_relu: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd_affine_relu: pixel count overflows int32");
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_conv3x3_fwd_affine_relu: bad dtype %d", dt);
+    hipStream_t st = (hipStream_t)stream;
+    bool done = false;
+    int rc;
+    if (dt == UH_BF16)
+        rc = conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w,
+                                          (bf16_t*)z, ldz, Cout, nullptr, B, H, W, st, scale, shift, &done);
+    else
+        rc = conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)z,
+                                         ldz, Cout, nullptr, B, H, W, st, scale, shift, &done);
+    if (rc != UH_OK || done) return rc;
+    return uh_bn_relu_apply(z, ldz, scale, shift, z, ldz, (int64_t)B * H * W, Cout, dt, stream);
 }
 
 // =====================================================================================

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
 from .utils.dice_score import dice_coeff
 
 
@@ -25,10 +26,10 @@ def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=Fals
             if net.n_classes == 1:
                 mask_true = torch.div(mask_true, 2, rounding_mode="floor")                      # evaluate.py:56
                 assert mask_true.min() >= 0 and mask_true.max() <= 1, "True mask indices should be in [0, 1]"
-                pred = (mask_pred.squeeze(1) > 0).float()          # sigmoid(x) > 0.5  <=>  x > 0   (evaluate.py:60-62)
+                pred = ops.threshold_mask(mask_pred.squeeze(1))    # sigmoid(x) > 0.5  <=>  x > 0   (evaluate.py:60-62)
                 d = dice_coeff(pred, mask_true, reduce_batch_first=False)
             else:
-                idx = mask_pred.argmax(dim=1)                                                   # evaluate.py:111
+                idx = ops.argmax_classes(mask_pred)                                             # evaluate.py:111
                 d = dice_coeff((idx == 2).float(), (mask_true == 2).float(), reduce_batch_first=False)
             dice_score += d
             if d < min_dice:

@@ -160,6 +160,25 @@ def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool):
     return wf, wd
 
 
+# Bumped by every optimizer step that writes parameters through raw pointers (FusedRMSprop): such writes do not touch
+# torch's version counters, and the inference path caches packed filters per parameter.
+WEIGHT_EPOCH = 0
+
+
+def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """KRSC filter pack for the inference forward, cached on the parameter until it changes."""
+    key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, dtype, tuple(weight.stride()))
+    hit = getattr(weight, "_uh_packed", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wf, _ = pack_w3x3(weight, dtype, False)
+    try:
+        weight._uh_packed = (key, wf)
+    except AttributeError:
+        pass
+    return wf
+
+
 def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, Cout: int,
                 want_stats: bool):
     B, H, W, C0 = x0.shape
@@ -270,7 +289,10 @@ class ConvBnReluFn(Function):
         if Cin != C0 + C1:
             raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
         need_dx = any(ctx.needs_input_grad[:2])
-        wf, wd = pack_w3x3(weight, x0.dtype, need_dx)
+        if training:
+            wf, wd = pack_w3x3(weight, x0.dtype, need_dx)
+        else:
+            wf, wd = packed_w3x3_cached(weight, x0.dtype), None
         dev = x0.device
         coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
         scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
@@ -285,11 +307,16 @@ class ConvBnReluFn(Function):
             if num_batches_tracked is not None:
                 num_batches_tracked.add_(1)
         else:
-            y, _, _ = conv3x3_fwd(x0, x1, wf, Cout, False)
+            # inference (model.eval(): evaluate.py:30, predict.py:17): running statistics -> per-channel scale/shift,
+            # applied with the ReLU inside the conv epilogue; nothing is kept for a backward pass
             LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(),
                      running_var.data_ptr(), float(eps), Cout, scale.data_ptr(), shift.data_ptr(), _stream())
-            mean.copy_(running_mean)
-            rstd.copy_(torch.rsqrt(running_var + eps))
+            z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
+            LIB.call("uh_conv3x3_fwd_affine_relu", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
+                     pixel_ld(x1) if x1 is not None else 0, wf.data_ptr(), z.data_ptr(), Cout, Cout, scale.data_ptr(),
+                     shift.data_ptr(), B, H, W, _dt(x0), _stream())
+            ctx.training = False
+            return z
         z = torch.empty_like(y)
         LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
                  n, Cout, _dt(y), _stream())
@@ -670,3 +697,27 @@ class DiceCoeffFn(Function):
         kb = torch.where(live, -(inter2 + eps) / (den * den), torch.zeros_like(den))
         dx = (ka[:, None] * tf.view(ngroups, group_len) + kb[:, None]) * (g / ngroups)
         return dx.view(shape).to(dtype), None, None, None, None
+
+
+# ----------------------------------------------------------------------------- inference masks
+def argmax_classes(mask_pred: torch.Tensor) -> torch.Tensor:
+    """`mask_pred.argmax(dim=1)` of predict.py:27 / evaluate.py:111 for logits [B,C,H,W] -> int64 [B,H,W]."""
+    _require_gpu(mask_pred, "logits")
+    if mask_pred.dim() != 4:
+        raise RuntimeError(f"argmax_classes expects [B,C,H,W] logits, got {tuple(mask_pred.shape)}")
+    B, C, H, W = mask_pred.shape
+    v = mask_pred.permute(0, 2, 3, 1)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    out = torch.empty(B, H, W, dtype=torch.int64, device=v.device)
+    LIB.call("uh_argmax_classes", v.data_ptr(), B * H * W, C, out.data_ptr(), _stream())
+    return out
+
+
+def threshold_mask(logits: torch.Tensor) -> torch.Tensor:
+    """`(torch.sigmoid(logits) > 0.5).float()` of evaluate.py:60-62, computed as logits > 0."""
+    _require_gpu(logits, "logits")
+    v = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+    out = torch.empty(v.shape, dtype=torch.float32, device=v.device)
+    LIB.call("uh_threshold_mask", v.data_ptr(), v.numel(), out.data_ptr(), _stream())
+    return out

@@ -130,6 +130,7 @@ class FusedRMSprop:
         LIB.call("uh_rmsprop_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_sq.data_ptr(),
                  self.flat_buf.data_ptr(), self.total, self.norm.data_ptr(), self.gradient_clipping, float(g["lr"]),
                  float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]), st)
+        ops.WEIGHT_EPOCH += 1        # parameters changed behind torch's version counters (see ops.packed_w3x3_cached)
         return self.norm
 
     def grad_of(self, p: torch.Tensor) -> torch.Tensor:
