@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="keep backward-weights on the launch stream (clean per-kernel durations under rocprofv3)")
     return ap.parse_args()
 
 
@@ -88,7 +90,7 @@ def main():
     torch.manual_seed(0)
     model = unet_amd.UNet(1, 1, bilinear=bilinear).to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
-    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream)
     g = torch.Generator().manual_seed(1 + rank)
     B, S = args.batch, args.size
     images = torch.rand(B, 1, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)

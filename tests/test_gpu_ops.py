@@ -116,7 +116,9 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,h,w,C,Ho,Wo", [(2, 32, 32, 64, 64, 64), (2, 12, 19, 64, 25, 39), (1, 8, 9, 8, 17, 19),
-                                           (2, 1, 1, 16, 2, 2), (1, 5, 7, 3, 10, 14), (2, 4, 4, 512, 8, 8)])
+                                           (2, 1, 1, 16, 2, 2), (1, 5, 7, 3, 10, 14), (2, 4, 4, 512, 8, 8),
+                                           (1, 40, 33, 16, 81, 67), (8, 64, 64, 64, 128, 128), (2, 2, 2, 8, 4, 4),
+                                           (1, 3, 2, 8, 7, 5), (4, 128, 96, 64, 256, 192), (1, 2, 9, 8, 4, 18)])
 def test_upsample_bilinear_pad(dtype, B, h, w, C, Ho, Wo):
     from unet_amd import ops
     dev = _dev()
@@ -133,7 +135,9 @@ def test_upsample_bilinear_pad(dtype, B, h, w, C, Ho, Wo):
     xg = _nhwc(x, dtype, dev).requires_grad_(True)
     y = ops.UpsampleBilinearPadFn.apply(xg, Ho, Wo)
     y.backward(_nhwc(cot, dtype, dev))
-    tol = 2e-6 if dtype == torch.float32 else 8e-3
+    # fp32: the interpolation weights are formed in fp32 like torch's float kernels (src = scale*dst, error ~ 6e-8*size)
+    # while the reference here is fp64
+    tol = max(4e-6, 1.5e-7 * max(Ho, Wo)) if dtype == torch.float32 else 8e-3
     assert _rel(y.permute(0, 3, 1, 2), ref.detach()) < tol
     assert _rel(xg.grad.permute(0, 3, 1, 2), dxref) < tol
 

@@ -11,7 +11,8 @@ from typing import Dict, List, Tuple
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, "include", "unet_hip.h")
-LIB_PATH = os.path.join(PKG_DIR, "libunet_hip.so")
+# UH_LIB_PATH points the binding at another build of the same C ABI (A/B kernel experiments)
+LIB_PATH = os.environ.get("UH_LIB_PATH") or os.path.join(PKG_DIR, "libunet_hip.so")
 
 UH_F32, UH_BF16 = 0, 1
 

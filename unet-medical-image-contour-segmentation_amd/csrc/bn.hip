@@ -190,12 +190,15 @@ extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, cons
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Thread = (pixel lane, channel group of V).  Block = a contiguous pixel range (blockIdx.x) x a slab of up to
-// 8 channel groups (blockIdx.y), so small feature maps with many channels still fill the chip.
+// Thread = (pixel lane, channel group of V).  Block = an interleaved set of 128-pixel chunks (blockIdx.x) x a slab of
+// up to 8 channel groups (blockIdx.y), so small feature maps with many channels still fill the chip.
 extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
-    (void)C;
-    int64_t n = (npix + 255) / 256;
-    if (n > 512) n = 512;
+    // >= ~2048 workgroups over (pixel chunks) x (64-channel slabs) when the map is large enough
+    int64_t slabs = (C + 63) / 64;
+    int64_t cap = 2048 / slabs;
+    if (cap < 512) cap = 512;
+    int64_t n = (npix + 127) / 128;
+    if (n > cap) n = cap;
     if (n < 1) n = 1;
     return (int)n;
 }
@@ -215,9 +218,6 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
     const int g = blockIdx.y * GB + g_in;
     const bool act = g < G;
     const int c = g * V;
-    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per;
-    const int64_t p1 = (p0 + per < npix) ? p0 + per : npix;
     float s1[V], s2[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -225,16 +225,30 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
         float sc[V], sh[V], mu[V], rs[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; }
-        for (int64_t p = p0 + pl; p < p1; p += PL) {
-            float d[V], yv[V];
-            uh_load<T, V>(dz + p * lddz + c, d);
-            uh_load<T, V>(y + p * ldy + c, yv);
+        // Workgroups interleave over chunks of U*PL pixels (grid-stride): neighbouring workgroups stream neighbouring
+        // addresses, so the concurrent streams spread over all HBM channels (one contiguous range per workgroup made
+        // them march in lockstep at a 2^k stride).  U pixels per trip = 2U 16-byte loads in flight per lane.
+        constexpr int U = 4;
+        for (int64_t p = (int64_t)blockIdx.x * (U * PL) + pl; p < npix; p += (int64_t)gridDim.x * (U * PL)) {
+            float d[U][V], yv[U][V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                float m = (fmaf(yv[i], sc[i], sh[i]) > 0.f) ? d[i] : 0.f;
-                s1[i] += m;
-                s2[i] += m * (yv[i] - mu[i]) * rs[i];
+            for (int u = 0; u < U; ++u) {
+                if (p + u * PL < npix) {
+                    uh_load<T, V>(dz + (p + u * PL) * lddz + c, d[u]);
+                    uh_load<T, V>(y + (p + u * PL) * ldy + c, yv[u]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) { d[u][i] = 0.f; yv[u][i] = 0.f; }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float m = (fmaf(yv[u][i], sc[i], sh[i]) > 0.f) ? d[u][i] : 0.f;
+                    s1[i] += m;
+                    s2[i] += m * (yv[u][i] - mu[i]) * rs[i];
+                }
         }
     }
 #pragma unroll
@@ -279,20 +293,25 @@ extern "C" int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, in
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double red[2][16][64];   // double: sum(dz) cancels heavily behind a BatchNorm
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // block = 16 channels x 64 row lanes (C/16 blocks: even a 64-channel layer spreads over 4 CUs and every thread
+    // walks only nblk/64 rows); double: sum(dz) cancels heavily behind a BatchNorm
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int s = sl; s < nblk; s += 16) {
+        for (int s = sl; s < nblk; s += 64) {
             a += (double)partials[((int64_t)s * 2 + 0) * C + c];
             b += (double)partials[((int64_t)s * 2 + 1) * C + c];
         }
-    red[0][sl][cl] = a;
-    red[1][sl][cl] = b;
+    // the four row lanes of a wave (lane bits 4,5), then the 16 waves through LDS
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    if ((threadIdx.x & 63) < 16) { red[0][wave][cl] = a; red[1][wave][cl] = b; }
     __syncthreads();
-    if (sl == 0 && c < C) {
+    if (threadIdx.x < 16 && c < C) {
         double x = 0.0, y = 0.0;
+#pragma unroll
         for (int k = 0; k < 16; ++k) { x += red[0][k][cl]; y += red[1][k][cl]; }
         dbeta[c] = (float)x;
         dgamma[c] = (float)y;
@@ -348,7 +367,7 @@ extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int
                "uh_bn_relu_bwd_apply: null pointer");
     UH_REQUIRE(npix > 0 && C > 0 && nblk > 0 && lddz >= C && ldy >= C && lddy >= C, "uh_bn_relu_bwd_apply: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
     UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     float inv_n = (float)(1.0 / (double)npix);
     UH_DISPATCH_DT(dt, T, {

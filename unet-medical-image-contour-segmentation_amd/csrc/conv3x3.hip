@@ -331,6 +331,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     constexpr int BN = NBW * 64;
     constexpr int NPIECE = HALO_PIX * 4;     // 1296
     constexpr int NLOAD = 6;
+#ifndef UH_FWD_PF
+#define UH_FWD_PF 1
+#endif
+    constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_BYTES];
 
@@ -358,13 +362,8 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const int nchunk = Cin / CK;
     const int ntile = B * tilesX * tilesY;
 
-    // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q)
-    int src_part[NLOAD];
-#pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        int p = tid + k * 256;
-        src_part[k] = ((p & 3) ^ halo_swz((p >> 2) % HALO_W)) * 16;
-    }
+    // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q).
+    // One register per slot: (global pixel index << 2) | source part, or -1 for a pixel outside the image.
     auto tile_pixels = [&](int tile, int (&pix)[NLOAD]) {
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             int hy = q / HALO_W, hx = q - hy * HALO_W;
             int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
             bool ok = (p < NPIECE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            pix[k] = ok ? ((b * H + gy) * W + gx) : -1;
+            pix[k] = ok ? ((((b * H + gy) * W + gx) << 2) | ((p & 3) ^ halo_swz(hx))) : -1;
         }
     };
     __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, (int)x0_bytes, 0x00020000);
@@ -393,7 +392,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         unsigned char* dst = lds + bufi * HALO2_BYTES + wave * 1024;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            unsigned voff = pix[k] >= 0 ? (unsigned)(pix[k] * ld * ES + src_part[k]) : OOB_OFFSET;
+            unsigned voff = pix[k] >= 0 ? (unsigned)((pix[k] >> 2) * ld * ES + (pix[k] & 3) * 16) : OOB_OFFSET;
             if (k < NLOAD - 1 || tid + k * 256 < NPIECE) {
                 if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     // Persistent over tiles: the DMA of the NEXT tile's first chunk is issued under the last chunk of the current
     // tile, so a workgroup never waits for a cold HBM round trip after its first tile (matters for the
     // HBM-bound 64-channel 512x512 layers, which have only 2 K-chunks per tile).
-    int pix_cur[NLOAD], pix_nxt[NLOAD];
+    int pix_cur[NLOAD];
     int tile = tile_lane;
     if (tile >= ntile) return;
     tile_pixels(tile, pix_cur);
@@ -432,8 +431,8 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             if (c + 1 < nchunk) {
                 dma_chunk(pix_cur, c + 1, bufi ^ 1);
             } else if (next_tile < ntile) {
-                tile_pixels(next_tile, pix_nxt);
-                dma_chunk(pix_nxt, 0, bufi ^ 1);
+                tile_pixels(next_tile, pix_cur);        // the current tile has no DMA left to issue
+                dma_chunk(pix_cur, 0, bufi ^ 1);
             }
             const unsigned char* buf = lds + bufi * HALO2_BYTES;
             const T* wcp = wl + c * CK;
@@ -453,12 +452,11 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
                 const unsigned char* xcol = buf + (lx + s) * 64 + ((kg ^ halo_swz(lx + s)) << 4);
                 auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
-                xf[0] = rd(0);
-                xf[1] = rd(1);
-                xf[2] = rd(2);
+#pragma unroll
+                for (int k = 0; k < 2 + PF; ++k) xf[k] = rd(k);
 #pragma unroll
                 for (int k = 2; k < 18; ++k) {
-                    if (k + 1 < 18) xf[k + 1] = rd(k + 1);
+                    if (k + PF < 18) xf[k + PF] = rd(k + PF);     // PF rows ahead of the row being multiplied
                     __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
                     const int i = k - 2;
 #pragma unroll
@@ -579,8 +577,6 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 }
             if (slab == 0 && tid == 0) stats[(int64_t)ntile * 2 * Cout + tile] = (float)(vy * vx);
         }
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k) pix_cur[k] = pix_nxt[k];
     }
 }
 

@@ -243,6 +243,78 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
     }
 }
 
+// Strip form of the same transpose (the hot variant).  Thread = (image, strip of `ty` input rows, input column ix, 16-byte
+// channel vector).  It walks the output rows uy that feed its strip in ascending order; per row it forms the column
+// pass t = sum_k wx[k] * dy[uy][2*ix-2+k] (the six candidates 2*ix-2 .. 2*ix+3 contain every output column that reads
+// input column ix when out = 2*in, align_corners=True: u*scale in [ix-1, ix+1) <=> u in [2ix-2-1/(n-1), 2ix+3+1/(n-1));
+// weights come from the forward's own up_coord, so this is the exact transpose) and adds l0*t / l1*t to the two input
+// rows i0(uy), i0(uy)+1 it feeds.  i0 is non-decreasing in uy, so two running accumulators suffice and every input
+// row is stored exactly once.  ~2.3 gathered 16-byte loads per stored element instead of the full window scan.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx,
+                                                                   int lddx, int B, int h, int w, int C, int Ho, int Wo,
+                                                                   int pt, int pl, float sy, float sx, int ty) {
+    constexpr int NC = 6;
+    const int G = C / V;
+    const int nstrip = (h + ty - 1) / ty;
+    const int64_t total = (int64_t)B * nstrip * w * G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t_ = idx;
+        const int c = (int)(t_ % G) * V; t_ /= G;
+        const int ix = (int)(t_ % w); t_ /= w;
+        const int strip = (int)(t_ % nstrip);
+        const int b = (int)(t_ / nstrip);
+        const int iy0 = strip * ty, iy1 = min(iy0 + ty, h);
+        const int uxb = 2 * ix - 2;
+        float wxs[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int ux = uxb + k, ox = ux + pl;
+            wxs[k] = (ux >= 0 && ux < 2 * w && ox >= 0 && ox < Wo) ? up_weight(ux, sx, w, ix) : 0.f;
+        }
+        const int uy_lo = max(0, 2 * iy0 - 2), uy_hi = min(2 * h - 1, 2 * (iy1 - 1) + 3);
+        float a0[V], a1[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+        int cur = up_coord(uy_lo, sy, h).i0;
+        T* dxp = dx + ((int64_t)b * h * w + ix) * lddx + c;
+        for (int uy = uy_lo; uy <= uy_hi; ++uy) {
+            const UpCoord cy = up_coord(uy, sy, h);
+            if (cy.i0 > cur) {              // row `cur` is complete (i0 advances by at most one per output row)
+                if (cur >= iy0 && cur < iy1) uh_store<T, V>(dxp + (int64_t)cur * w * lddx, a0);
+#pragma unroll
+                for (int i = 0; i < V; ++i) { a0[i] = a1[i]; a1[i] = 0.f; }
+                cur = cy.i0;
+            }
+            const int oy = uy + pt;
+            if (oy < 0 || oy >= Ho) continue;
+            const T* row = dy + ((int64_t)(b * Ho + oy) * Wo + uxb + pl) * lddy + c;
+            float tt[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) tt[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (wxs[k] != 0.f) {
+                    float g[V];
+                    uh_load<T, V>(row + (int64_t)k * lddy, g);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) tt[i] = fmaf(wxs[k], g[i], tt[i]);
+                }
+            }
+            if (cy.i1 == cy.i0) {
+                const float wsum = cy.l0 + cy.l1;
+#pragma unroll
+                for (int i = 0; i < V; ++i) a0[i] = fmaf(wsum, tt[i], a0[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) { a0[i] = fmaf(cy.l0, tt[i], a0[i]); a1[i] = fmaf(cy.l1, tt[i], a1[i]); }
+            }
+        }
+        if (cur >= iy0 && cur < iy1) uh_store<T, V>(dxp + (int64_t)cur * w * lddx, a0);
+        if (cur + 1 >= iy0 && cur + 1 < iy1) uh_store<T, V>(dxp + (int64_t)(cur + 1) * w * lddx, a1);
+    }
+}
+
 static inline float up_scale(int in) { return (2 * in > 1) ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
 
 extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B, int h, int w, int C, int Ho, int Wo,
@@ -273,7 +345,14 @@ extern "C" int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
     float sy = up_scale(h), sx = up_scale(w);
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C))
+        if (uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C) && h >= 2 && w >= 2) {
+            // strips of 16 input rows; shorter strips on small maps keep >= ~1024 workgroups in flight
+            int ty = 16;
+            while (ty > 2 && (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC) < 256 * 1024) ty >>= 1;
+            const int64_t nthr = (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC);
+            hipLaunchKernelGGL((upsample2x_bwd_strip_kernel<T, VEC>), dim3(pu_grid(nthr)), dim3(256), 0, st, (const T*)dy,
+                               lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, ty);
+        } else if (uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C))
             hipLaunchKernelGGL((upsample2x_bwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
                                (const T*)dy, lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
         else
