@@ -367,3 +367,26 @@ def test_missing_gpu_tensor_fails_loudly():
     m = unet_amd.DoubleConv(3, 8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randn(1, 3, 8, 8))
+
+
+def test_nan_loss_raises_and_leaves_parameters_untouched():
+    """train.py:149-151: a NaN loss is fatal.  The flag is read after backward has been enqueued (train.py docstring of
+    train_step) but before the optimizer step, so the parameters must be bit-identical afterwards."""
+    import unet_amd
+    dev = _dev()
+    torch.manual_seed(0)
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-3, amp=False)
+    before = {k: v.clone() for k, v in model.state_dict().items() if v.is_floating_point() and "running" not in k}
+    images = torch.rand(2, 1, 32, 32).to(dev)
+    images[0, 0, 3, 3] = float("nan")
+    masks = torch.randint(0, 3, (2, 32, 32)).to(dev)
+    with pytest.raises(RuntimeError, match="NaN loss"):
+        stepper.step(images, masks)
+    torch.cuda.synchronize()
+    for k, v in before.items():
+        assert torch.equal(model.state_dict()[k], v), k
+    # and the stepper still works afterwards
+    images = torch.rand(2, 1, 32, 32).to(dev)
+    out = stepper.step(images, masks)
+    assert torch.isfinite(out["loss"]).all()

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
         uh_load<T, V>(y + p * ldy + c, v);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            if constexpr (HOIST) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
-            else v[i] = fmaxf(fmaf(v[i], scale[c + i], shift[c + i]), 0.f);
+            if constexpr (HOIST) v[i] = uh_relu(fmaf(v[i], sc[i], sh[i]));
+            else v[i] = uh_relu(fmaf(v[i], scale[c + i], shift[c + i]));
         }
         uh_store<T, V>(z + p * ldz + c, v);
     }
@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
                                                                  float* __restrict__ partials, int64_t npix, int C) {
     constexpr int GB = 8;                             // channel groups per block
     constexpr int PL = 256 / GB;                      // 32 pixel lanes
-    __shared__ float red[PL][2][GB * V];
+    // 2 KB of LDS only: this kernel is meant to run beside the backward-weights conv of the previous layer (side
+    // stream), whose two workgroups per CU leave ~4 KB of the CU's 160 KB
+    __shared__ float red[4][2][GB * V];
     const int G = C / V;
     const int g_in = threadIdx.x % GB, pl = threadIdx.x / GB;
     const int g = blockIdx.y * GB + g_in;
@@ -251,21 +253,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
                 }
         }
     }
+    // the 8 pixel lanes of a wave (lane bits 3..5) by shuffles, then the 4 waves through LDS
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        red[pl][0][g_in * V + i] = s1[i];
-        red[pl][1][g_in * V + i] = s2[i];
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < GB) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            red[wave][0][g_in * V + i] = s1[i];
+            red[wave][1][g_in * V + i] = s2[i];
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * GB * V; k += 256) {
         const int which = k / (GB * V), cc = k - which * (GB * V);
         const int ch = blockIdx.y * GB * V + cc;
-        if (ch < C) {
-            float v = 0.f;
-#pragma unroll 8
-            for (int q = 0; q < PL; ++q) v += red[q][which][cc];
-            partials[((int64_t)blockIdx.x * 2 + which) * C + ch] = v;
-        }
+        if (ch < C)
+            partials[((int64_t)blockIdx.x * 2 + which) * C + ch] =
+                (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
     }
 }
 

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][n][j] = fmaxf(fmaf(acc[i][n][j], sc[j], sh[j]), 0.f);
+                    for (int j = 0; j < 4; ++j) acc[i][n][j] = uh_relu(fmaf(acc[i][n][j], sc[j], sh[j]));
             }
         }
         float ssum[NBW][4];
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
                     }
             if (ep_scale) {
 #pragma unroll
-                for (int i = 0; i < V; ++i) a[i] = fmaxf(fmaf(a[i], esc[i], esh[i]), 0.f);
+                for (int i = 0; i < V; ++i) a[i] = uh_relu(fmaf(a[i], esc[i], esh[i]));
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) out[j][i] = uh_round_as<T>(a[i]);

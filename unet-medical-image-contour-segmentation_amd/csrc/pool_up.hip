@@ -27,13 +27,13 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
         uh_load<T, V>(base, a);
         uh_load<T, V>(base + ldx, t);
 #pragma unroll
-        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        for (int i = 0; i < V; ++i) a[i] = uh_max_nan(a[i], t[i]);
         uh_load<T, V>(base + (int64_t)W * ldx, t);
 #pragma unroll
-        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        for (int i = 0; i < V; ++i) a[i] = uh_max_nan(a[i], t[i]);
         uh_load<T, V>(base + (int64_t)W * ldx + ldx, t);
 #pragma unroll
-        for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], t[i]);
+        for (int i = 0; i < V; ++i) a[i] = uh_max_nan(a[i], t[i]);
         uh_store<T, V>(y + p * ldy + c, a);
     }
 }
@@ -69,9 +69,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
             for (int i = 0; i < V; ++i) {
                 int arg = 0;
                 float m = v0[i];
-                if (v1[i] > m) { m = v1[i]; arg = 1; }
-                if (v2[i] > m) { m = v2[i]; arg = 2; }
-                if (v3[i] > m) { m = v3[i]; arg = 3; }
+                // torch's rule: (val > max) || isnan(val) -- a NaN takes the window, the last NaN wins
+                if (v1[i] > m || v1[i] != v1[i]) { m = v1[i]; arg = 1; }
+                if (v2[i] > m || v2[i] != v2[i]) { m = v2[i]; arg = 2; }
+                if (v3[i] > m || v3[i] != v3[i]) { m = v3[i]; arg = 3; }
                 if (arg == me) o[i] += g[i];
             }
         }

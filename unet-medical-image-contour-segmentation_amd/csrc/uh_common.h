@@ -70,6 +70,11 @@ template <> struct uh_vec16<bf16_t> {
     __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
 };
 
+// NaN-propagating max (torch.relu / max_pool2d keep a NaN; fmaxf would launder it into a number and the NaN-loss
+// check of train.py:149-151 could never fire).  One v_maximum3_f32 on gfx950.
+__device__ __forceinline__ float uh_max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float uh_relu(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+
 __device__ __forceinline__ float uh_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -348,6 +348,15 @@ class ConvBnReluFn(Function):
         LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
                  dbeta.data_ptr(), dy.data_ptr(), Cout, n, Cout, dt, _stream())
+        # backward-data first: it is the only consumer on the critical path (the next layer's BatchNorm backward waits
+        # for it).  Backward-weights then goes to the side stream BEHIND it, so that it runs beside the HBM-bound
+        # kernels of the layers that follow (BatchNorm backward, pool / upsample backward) instead of beside this
+        # layer's own MFMA-bound backward-data.
+        dx0 = dx1 = None
+        if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False)
+            dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
+            dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
         dweight = None
         if ctx.needs_input_grad[2]:
@@ -355,7 +364,7 @@ class ConvBnReluFn(Function):
             if cb_w is not None and WGRAD_STREAM is not None and _is_krsc_dense(weight):
                 side = WGRAD_STREAM
                 ev = torch.cuda.Event()
-                ev.record()                         # dy is complete on the main stream at this point
+                ev.record()                         # dy (and this layer's backward-data) are enqueued before this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     conv3x3_wgrad(dy, x0, x1, dweight)
@@ -378,11 +387,6 @@ class ConvBnReluFn(Function):
         if cb_b is not None:
             cb_b()
             dbeta = None
-        dx0 = dx1 = None
-        if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False)
-            dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
-            dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None
 
 

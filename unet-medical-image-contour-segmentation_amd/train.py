@@ -174,10 +174,22 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
         terms = seg_loss(masks_pred, true_masks, model.n_classes, reduce_sums=reduce_sums, world=world,
                          boundary_weight=boundary_weight)
     loss = terms["loss"]
-    if check_nan and bool(torch.isnan(loss).any()):
-        raise RuntimeError("Fatal: NaN loss detected!")                                       # train.py:149-151
+    nan_host = nan_event = None
+    if check_nan:
+        # train.py:149-151 raises before backward().  Reading the flag right here would stall the host until the
+        # forward has drained and leave the GPU idle while backward is being enqueued, so the flag travels to pinned
+        # memory asynchronously and is read after backward has been ENQUEUED, still before the optimizer step: a NaN
+        # loss raises the same error and never reaches the parameters.
+        nan_host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+        nan_host.copy_(torch.isnan(loss.detach()).reshape(1), non_blocking=True)
+        nan_event = torch.cuda.Event()
+        nan_event.record()
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    if nan_event is not None:
+        nan_event.synchronize()
+        if bool(nan_host.item()):
+            raise RuntimeError("Fatal: NaN loss detected!")                                   # train.py:149-151
     if isinstance(optimizer, FusedRMSprop):
         terms["grad_norm"] = optimizer.step()
     else:
