@@ -50,8 +50,9 @@ int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int
  * y[b,h,w,o] = sum_{r,s,i} x[b,h+r-1,w+s-1,i] * w[o][r][s][i]; the input is the virtual channel
  * concat of (x0:C0) and (x1:C1) (x1 may be NULL with C1 = 0).
  * stat_partials (may be NULL): nslab = uh_conv3x3_stat_slabs(); fp32 [nslab][2][Cout] per-slab
- * (mean, M2 = sum (y - mean)^2) of the STORED y over the slab's pixels, then [nslab] pixel counts,
- * then [nslab] scratch for uh_bn_finalize: nslab*(2*Cout + 2) floats.  These are BatchNorm2d's batch
+ * (mean, M2 = sum (y - mean)^2) of the STORED y over the slab's pixels, then [nslab] pixel counts
+ * (a kernel that needs fewer slabs writes 0 counts for the rest), then [nslab] scratch:
+ * nslab*(2*Cout + 2) floats.  These are BatchNorm2d's batch
  * statistics (unet_parts.py:16,19) without a second pass over y.  With w = w_dgrad this is conv
  * backward-data. */
 int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int dt);
@@ -73,11 +74,12 @@ int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
 /* ---- nn.BatchNorm2d + nn.ReLU(inplace)  (unet_parts.py:16-17,19-20) ------------------------
  * finalize: merge the conv's stat slabs (Chan's formula, double) -> mean, rstd = 1/sqrt(var_biased + eps),
  * scale = gamma*rstd, shift = beta - mean*scale; running stats (may be NULL) updated in place with
- * `momentum` and the UNBIASED variance (n = pixels per channel). */
+ * `momentum` and the UNBIASED variance (n = pixels per channel); *num_batches_tracked (int64 on the
+ * device, may be NULL) += 1.  Slab rows whose pixel count is 0 are ignored. */
 int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,
                    const float* gamma, const float* beta, float* running_mean, float* running_var,
-                   float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
-                   uh_stream stream);
+                   int64_t* num_batches_tracked, float momentum, float eps,
+                   float* scale, float* shift, float* mean, float* rstd, uh_stream stream);
 /* eval mode: scale/shift from the running statistics. */
 int uh_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift,

@@ -22,58 +22,65 @@ __device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, dou
     a.n = n;
 }
 
-// fold: in place, entry f*L <- merge of slabs [f*L, min((f+1)*L, nslab))
-__global__ __launch_bounds__(256) void bn_stats_fold_kernel(float* __restrict__ stats, int nslab, int C, int L) {
-    __shared__ double red[3][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int f = blockIdx.y;
-    const int s0 = f * L, s1 = min(s0 + L, nslab);
+// Rows with a zero pixel count are skipped (producers that use fewer rows than
+// the buffer holds zero the counts of the rest); the number of leading rows to walk is found first.  Chan merge in
+// double, then the affine coefficients, the running statistics and num_batches_tracked.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int C, double n,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                           long long* __restrict__ nbt) {
+    // block = 16 channels x 64 row lanes (C/16 blocks, each thread walks R/64 rows)
+    __shared__ double red[3][16][16];
+    __shared__ int last_row;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 16 + cl;
     const float* cnt = stats + (int64_t)nslab * 2 * C;
-    Moments m = {0.0, 0.0, 0.0};
-    if (c < C)
-        for (int s = s0 + sl; s < s1; s += 4)
-            chan_merge(m, (double)cnt[s], (double)stats[((int64_t)s * 2 + 0) * C + c], (double)stats[((int64_t)s * 2 + 1) * C + c]);
-    red[0][sl][cl] = m.n; red[1][sl][cl] = m.mean; red[2][sl][cl] = m.m2;
+    if (threadIdx.x == 0) last_row = -1;
     __syncthreads();
-    if (sl == 0) {
-        for (int k = 1; k < 4; ++k) chan_merge(m, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
-        if (c < C) {
-            stats[((int64_t)s0 * 2 + 0) * C + c] = (float)m.mean;
-            stats[((int64_t)s0 * 2 + 1) * C + c] = (float)m.m2;
+    int last = -1;
+    for (int s = threadIdx.x; s < nslab; s += 1024)
+        if (cnt[s] > 0.f) last = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if ((threadIdx.x & 63) == 0 && last >= 0) atomicMax(&last_row, last);
+    __syncthreads();
+    const int R = last_row + 1;
+    // Two passes over the (L2-resident) rows instead of a chain of Chan merges (each merge costs a double division):
+    //   mean = sum_i n_i*mean_i / N,   M2 = sum_i [ M2_i + n_i*(mean_i - mean)^2 ]
+    // cross-lane sums: the 4 row lanes of a wave by shuffles (lane bits 4,5), the 16 waves through LDS
+    auto block_sum = [&](double v, int slot) -> double {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if ((threadIdx.x & 63) < 16) red[slot][wave][cl] = v;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[slot][k][cl];
+        return t;
+    };
+    double a = 0.0, cn = 0.0;
+    if (c < C)
+        for (int f = sl; f < R; f += 64) {
+            const double nf = (double)cnt[f];
+            if (nf > 0.0) { a = fma(nf, (double)stats[((int64_t)f * 2 + 0) * C + c], a); cn += nf; }
         }
-    }
-    __syncthreads();
-    // counts are shared by all channels: the block with blockIdx.x == 0 folds them AFTER every thread of
-    // THIS block has read them; other channel blocks may still be reading -> write to a shadow slot
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double n = 0.0;
-        for (int s = s0; s < s1; ++s) n += (double)cnt[s];
-        stats[(int64_t)nslab * 2 * C + nslab + f] = (float)n;       // folded counts live after the raw counts
-    }
-}
-
-// block = 64 channels x 4 fold lanes; Chan merge in double, then the affine coefficients and running statistics
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int nfold, int L, int C,
-                                                          double n, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, float momentum, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift,
-                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-    __shared__ double red[3][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const float* cnt = stats + (int64_t)nslab * 2 * C + (L > 1 ? nslab : 0);
-    Moments m = {0.0, 0.0, 0.0};
+    const double A = block_sum(a, 0), N = block_sum(cn, 1);
+    const double mean = N > 0.0 ? A / N : 0.0;
+    double q = 0.0;
     if (c < C)
-        for (int f = sl; f < nfold; f += 4)
-            chan_merge(m, (double)cnt[f], (double)stats[((int64_t)f * L * 2 + 0) * C + c],
-                       (double)stats[((int64_t)f * L * 2 + 1) * C + c]);
-    red[0][sl][cl] = m.n; red[1][sl][cl] = m.mean; red[2][sl][cl] = m.m2;
-    __syncthreads();
+        for (int f = sl; f < R; f += 64) {
+            const double nf = (double)cnt[f];
+            if (nf > 0.0) {
+                const double d = (double)stats[((int64_t)f * 2 + 0) * C + c] - mean;
+                q += (double)stats[((int64_t)f * 2 + 1) * C + c] + nf * d * d;
+            }
+        }
+    Moments m = {N, mean, block_sum(q, 2)};
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;            // unet_parts.py:16: BatchNorm2d bookkeeping
     if (sl != 0 || c >= C) return;
-    for (int k = 1; k < 4; ++k) chan_merge(m, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
-    double mean = m.mean;
     double var = m.m2 / n;                      // biased
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma[c], bt = beta[c];
@@ -90,22 +97,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n, const float* gamma,
-                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                              float* scale, float* shift, float* mean, float* rstd, uh_stream stream) {
+                              const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                              uh_stream stream) {
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
     UH_REQUIRE(nslab > 0 && C > 0 && n > 0, "uh_bn_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    int L = 1, nfold = nslab;
-    if (nslab > 64) {
-        L = (nslab + 127) / 128;
-        if (L < 2) L = 2;
-        nfold = (nslab + L - 1) / L;
-        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + 63) / 64, nfold), dim3(256), 0, st, (float*)stat_partials,
-                           nslab, C, L);
-        UH_CHECK_LAUNCH("bn_stats_fold_kernel");
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stat_partials, nslab, nfold, L, C,
-                       (double)n, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, (double)n, gamma,
+                       beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
+                       (long long*)num_batches_tracked);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
     return UH_OK;
 }

@@ -337,6 +337,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_BYTES];
+    // running (mean, M2) of this workgroup's channels over all the tiles it has finished: one BatchNorm partial row
+    // per WORKGROUP (<= 768 rows) instead of one per tile (8192 rows for a 512x512 batch of 8)
+    __shared__ float wg_mom[2][BN];
+    float n_run = 0.f;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -569,13 +573,40 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                         a += ok ? d * d : 0.f;
                     }
                     a = uh_row16_sum(a);
-                    if (lx == 0) {
-                        const int ch = co_w + n * 16 + kg * 4 + j;
-                        stats[((int64_t)tile * 2 + 0) * Cout + ch] = mu;
-                        stats[((int64_t)tile * 2 + 1) * Cout + ch] = a;
+                    if (lx == 0) {       // Chan merge of (count, mean, M2) into the workgroup's running moments; the
+                        const int cl = wave * (NBW * 16) + n * 16 + kg * 4 + j;      // same lane owns the slot every tile
+                        const float nb = (float)(vy * vx);
+                        if (n_run == 0.f) {
+                            wg_mom[0][cl] = mu;
+                            wg_mom[1][cl] = a;
+                        } else {
+                            const float ma = wg_mom[0][cl], tot = n_run + nb, d = mu - ma;
+                            wg_mom[0][cl] = ma + d * (nb / tot);
+                            wg_mom[1][cl] += a + d * d * (n_run * nb / tot);
+                        }
                     }
                 }
-            if (slab == 0 && tid == 0) stats[(int64_t)ntile * 2 * Cout + tile] = (float)(vy * vx);
+            n_run += (float)(vy * vx);
+        }
+    }
+    if (stats) {
+        // row = tile lane of this workgroup; rows nlanes .. ntile-1 of the (per-tile sized) buffer get a zero pixel
+        // count, which uh_bn_finalize skips
+        if (lx == 0) {
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = wave * (NBW * 16) + n * 16 + kg * 4 + j;
+                    stats[((int64_t)tile_lane * 2 + 0) * Cout + co_blk + cl] = wg_mom[0][cl];
+                    stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = wg_mom[1][cl];
+                }
+        }
+        float* counts = stats + (int64_t)ntile * 2 * Cout;
+        if (slab == 0) {
+            if (tid == 0) counts[tile_lane] = n_run;
+            if (tile_lane == 0)
+                for (int r = nlanes + tid; r < ntile; r += 256) counts[r] = 0.f;
         }
     }
 }

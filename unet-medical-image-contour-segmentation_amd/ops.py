@@ -301,11 +301,13 @@ class ConvBnReluFn(Function):
         b32 = beta if beta.dtype == torch.float32 else beta.float()
         if training:
             y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True)
+            nbt = num_batches_tracked
+            fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
             LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(),
-                     _p(running_mean), _p(running_var), float(momentum), float(eps), scale.data_ptr(),
-                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
-            if num_batches_tracked is not None:
-                num_batches_tracked.add_(1)
+                     _p(running_mean), _p(running_var), nbt.data_ptr() if fused_nbt else None, float(momentum),
+                     float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+            if nbt is not None and not fused_nbt:
+                nbt.add_(1)
         else:
             # inference (model.eval(): evaluate.py:30, predict.py:17): running statistics -> per-channel scale/shift,
             # applied with the ReLU inside the conv epilogue; nothing is kept for a backward pass
