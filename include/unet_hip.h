@@ -42,6 +42,10 @@ int uh_version(void);
  * [I][3][3][O] (w_dgrad, may be NULL) that turns conv3x3_fwd into the data-gradient conv. */
 int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
                  void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
+/* All layers at once: table = nlayers x 8 int64 on the DEVICE {w pointer, sO, sI, sH, sW, Cout, Cin, first element of
+ * the layer in the flat outputs}; total = sum of Cout*9*Cin.  w_dgrad_flat may be NULL. */
+int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t total, void* w_fwd_flat,
+                         void* w_dgrad_flat, int dt, uh_stream stream);
 /* KRSC fp32 weight gradient -> gradient tensor with the parameter's own strides. */
 int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int64_t sH, int64_t sW,
                     int Cout, int Cin, uh_stream stream);

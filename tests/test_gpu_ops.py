@@ -305,3 +305,35 @@ def test_rmsprop_clip_flat():
     assert abs(float(nrm) - float(norm)) < 1e-6 * float(norm)
     assert _rel(pg[:n], pr) < 1e-6 and _rel(sg[:n], sqr) < 1e-5 and _rel(bg[:n], bufr) < 1e-5
     assert _rel(gg[:n], (gr * coef).double()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_weight_pack_matches_per_layer(dtype):
+    """uh_pack_w3x3_batched (one launch for every 3x3 filter of a model) == uh_pack_w3x3 per layer, for contiguous and
+    channels_last parameters, and the cache notices parameter updates."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 1), (64, 64), (128, 64), (16, 24), (8, 3), (256, 128)]
+    ws = []
+    for k, (o, i) in enumerate(shapes):
+        w = torch.randn(o, i, 3, 3, generator=g).to(dev)
+        if k % 2:
+            w = w.contiguous(memory_format=torch.channels_last)
+        ws.append(w)
+    pack = ops.ConvWeightPack(ws, dtype)
+    pack.refresh()
+    for w in ws:
+        hit = pack.lookup(w, dtype)
+        assert hit is not None
+        wf, wd = ops.pack_w3x3(w, dtype, True)
+        assert torch.equal(hit[0], wf) and torch.equal(hit[1], wd)
+    assert pack.lookup(ws[0], torch.float32 if dtype == torch.bfloat16 else torch.bfloat16) is None
+    ws[2].mul_(2.0)                                   # torch-side update: version counter moves -> miss until refreshed
+    assert pack.lookup(ws[2], dtype) is None
+    pack.refresh()
+    wf, wd = ops.pack_w3x3(ws[2], dtype, True)
+    hit = pack.lookup(ws[2], dtype)
+    assert torch.equal(hit[0], wf) and torch.equal(hit[1], wd)
+    ops.WEIGHT_EPOCH += 1                             # raw-pointer optimizer update -> every entry is stale
+    assert pack.lookup(ws[0], dtype) is None

@@ -179,6 +179,58 @@ def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor
     return wf
 
 
+class ConvWeightPack:
+    """Packed (KRSC forward + flipped/transposed backward-data) copies of ALL 3x3 filters of a model, refreshed by one
+    kernel launch per train step (TrainStepper) instead of one launch per layer inside the forward."""
+
+    def __init__(self, weights, dtype: torch.dtype):
+        self.weights = [w for w in weights if w.dim() == 4 and w.shape[2:] == (3, 3) and w.dtype == torch.float32 and w.is_cuda]
+        self.dtype = dtype
+        self.epoch = -1
+        self._build()
+
+    def _build(self):
+        dev = self.weights[0].device
+        rows, off = [], 0
+        self.offsets = []
+        for w in self.weights:
+            O, I = w.shape[0], w.shape[1]
+            sO, sI, sH, sW = w.stride()
+            rows.append([w.data_ptr(), sO, sI, sH, sW, O, I, off])
+            self.offsets.append(off)
+            off += O * 9 * I
+        self.total = off
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.ptrs = [w.data_ptr() for w in self.weights]
+        self.strides = [tuple(w.stride()) for w in self.weights]
+        self.wf = torch.empty(self.total, dtype=self.dtype, device=dev)
+        self.wd = torch.empty(self.total, dtype=self.dtype, device=dev)
+        self.versions = [None] * len(self.weights)
+        self.index = {p: i for i, p in enumerate(self.ptrs)}
+
+    def refresh(self):
+        if any(w.data_ptr() != p or tuple(w.stride()) != st for w, p, st in zip(self.weights, self.ptrs, self.strides)):
+            self._build()                       # a parameter was re-allocated (.to(), load with assign=True, ...)
+        LIB.call("uh_pack_w3x3_batched", self.table.data_ptr(), len(self.weights), self.total, self.wf.data_ptr(),
+                 self.wd.data_ptr(), UH_BF16 if self.dtype == torch.bfloat16 else UH_F32, _stream())
+        self.versions = [w._version for w in self.weights]
+        self.epoch = WEIGHT_EPOCH
+
+    def lookup(self, weight: torch.Tensor, dtype: torch.dtype):
+        """-> (w_fwd, w_dgrad) views if the pack holds the CURRENT value of `weight` in `dtype`, else None."""
+        i = self.index.get(weight.data_ptr())
+        if i is None or dtype != self.dtype or self.epoch != WEIGHT_EPOCH or self.versions[i] != weight._version \
+                or self.strides[i] != tuple(weight.stride()):
+            return None
+        n = weight.shape[0] * 9 * weight.shape[1]
+        o = self.offsets[i]
+        return self.wf[o:o + n], self.wd[o:o + n]
+
+
+# set by TrainStepper (one pack per model being trained); ConvBnReluFn falls back to per-layer packing on a miss
+WEIGHT_PACK: Optional[ConvWeightPack] = None
+
+
 def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, Cout: int,
                 want_stats: bool):
     B, H, W, C0 = x0.shape
@@ -290,7 +342,8 @@ class ConvBnReluFn(Function):
             raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
         need_dx = any(ctx.needs_input_grad[:2])
         if training:
-            wf, wd = pack_w3x3(weight, x0.dtype, need_dx)
+            hit = WEIGHT_PACK.lookup(weight, x0.dtype) if WEIGHT_PACK is not None else None
+            wf, wd = hit if hit is not None else pack_w3x3(weight, x0.dtype, need_dx)
         else:
             wf, wd = packed_w3x3_cached(weight, x0.dtype), None
         dev = x0.device

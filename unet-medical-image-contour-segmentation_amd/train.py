@@ -215,9 +215,18 @@ class TrainStepper:
         self.reduce_sums = dpmod.make_sum_reducer(process_group)
         self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
                                       gradient_clipping=gradient_clipping, process_group=process_group)
+        self._pack = None
 
     def step(self, images, true_masks):
         self.model.train()
+        # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
+        dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
+        if self._pack is None or self._pack.dtype != dt:
+            ws = [m.weight for m in self.model.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)]
+            self._pack = ops.ConvWeightPack(ws, dt) if ws and all(w.is_cuda for w in ws) else None
+        if self._pack is not None:
+            ops.WEIGHT_PACK = self._pack
+            self._pack.refresh()
         return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
                           reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan)
 
