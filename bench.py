@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank flow on a one-GPU box together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="keep backward-weights on the launch stream (clean per-kernel durations under rocprofv3)")
     return ap.parse_args()
@@ -77,12 +80,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the train-step path has no CPU fallback")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     import unet_amd
     from unet_amd import ops
 
@@ -114,19 +122,21 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(last["loss"])
+    loss = float(last["loss"].detach())
 
     # ---- dominant-kernel roofline, measured live with events on the launch stream (one extra step)
     roof = None
     kernels = None
-    if rank == 0 and not args.no_kernel_profile:
+    if not args.no_kernel_profile:
+        # EVERY rank runs this extra step (it contains the gradient / loss-sum collectives); rank 0 records events
         ops.PROFILE.clear()
-        ops.PROFILE_ON = True
+        ops.PROFILE_ON = rank == 0
         side, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None      # time every kernel alone on the launch stream
         stepper.step(images, masks)
         torch.cuda.synchronize()
         ops.WGRAD_STREAM = side
         ops.PROFILE_ON = False
+    if rank == 0 and not args.no_kernel_profile:
         agg = {}
         for name, flops, e0, e1 in ops.PROFILE:
             a = agg.setdefault(name, [0, 0.0, 0.0])
