@@ -73,6 +73,39 @@ def cpu_baseline(size: int):
                       f"1 warm-up + best of {nsteps} steps ({best:.2f} s/step)"}
 
 
+def dice_vs_ref(steps: int = 120, size: int = 64, batch: int = 4, lr: float = 1e-4):
+    """BASELINE metric's second half, "Dice vs ref": the same `steps` train steps of UNet_T(1,1,bilinear) on seeded
+    synthetic ellipse batches run by the CPU oracle (reference restatement) and by the HIP path (fp32 and bf16), then the
+    evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here)."""
+    import unet_amd
+    from oracle import step_ref as S
+    from oracle import unet_ref as U
+    torch.set_num_threads(min(16, os.cpu_count() or 1))            # tiny tensors: the box's 100+ cores only add overhead
+    widths = (8, 16, 32, 64, 128)                                  # UNet_T (unet_model.py:52-82)
+    train = [unet_amd.ellipse_batch(batch, size, seed=100 + i) for i in range(4)]
+    held = unet_amd.ellipse_batch(8, size, seed=7)
+    st = U.init_state(1, 1, True, widths=widths, seed=0)
+    init = {k: v.clone() for k, v in st.items()}
+    opt = None
+    for i in range(steps):
+        im, mk = train[i % len(train)]
+        st, opt, _ = S.train_step(st, opt, im, mk, n_classes=1, bilinear=True, lr=lr)
+    d_ref, _ = S.evaluate_dice(st, held[0], held[1], n_classes=1, bilinear=True)
+    out = {"model": f"UNet_T(1,1,bilinear) {batch}x1x{size}x{size}", "steps": steps, "lr": lr, "ref_cpu_fp32": round(float(d_ref), 4)}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for name, amp in (("hip_fp32", False), ("hip_bf16", True)):
+        model = unet_amd.UNet_T(1, 1, bilinear=True)
+        model.load_state_dict({k: v.clone() for k, v in init.items()})
+        model = model.to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=lr, amp=amp)
+        for i in range(steps):
+            im, mk = train[i % len(train)]
+            stepper.step(im.to(dev), mk.to(dev))
+        d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp)
+        out[name] = round(float(d), 4)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +216,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"]["dice_vs_ref"] = dice_vs_ref()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

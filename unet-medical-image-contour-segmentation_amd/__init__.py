@@ -8,3 +8,4 @@ from .train import FusedRMSprop, seg_loss, train_step, TrainStepper  # noqa: F40
 from .evaluate import evaluate  # noqa: F401
 from .predict import predict_img, mask_to_image, preprocess_image  # noqa: F401
 from .checkpoint import save_checkpoint, load_checkpoint  # noqa: F401
+from .synthetic import ellipse_batch  # noqa: F401
