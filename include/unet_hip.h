@@ -42,9 +42,10 @@ int uh_version(void);
  * [I][3][3][O] (w_dgrad, may be NULL) that turns conv3x3_fwd into the data-gradient conv. */
 int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
                  void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
-/* All layers at once: table = nlayers x 8 int64 on the DEVICE {w pointer, sO, sI, sH, sW, Cout, Cin, first element of
- * the layer in the flat outputs}; total = sum of Cout*9*Cin.  w_dgrad_flat may be NULL. */
-int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t total, void* w_fwd_flat,
+/* All layers at once: table = nlayers x 10 int64 on the DEVICE {w pointer, sO, sI, sH, sW, Cout, Cin, first element
+ * of the layer in the flat outputs, first tile of the layer, 0}; a layer has ceil(Cout/32)*ceil(Cin/32)*9 tiles and
+ * ntiles is their sum.  w_dgrad_flat may be NULL. */
+int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t ntiles, void* w_fwd_flat,
                          void* w_dgrad_flat, int dt, uh_stream stream);
 /* KRSC fp32 weight gradient -> gradient tensor with the parameter's own strides. */
 int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int64_t sH, int64_t sW,
@@ -132,6 +133,24 @@ size_t uh_convt2x2_wgrad_ws_bytes(int B, int h, int w_, int Cin, int Cout);
 int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, float* dbias,
                       void* ws, size_t ws_bytes, int B, int h, int w_, int Cin, int Cout,
                       int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
+
+/* MFMA path of the same layer (csrc/convt_mfma.hip): all three directions as K-contiguous GEMMs over pixels.
+ * uh_convt2x2_mfma_ok() tells whether a problem qualifies (channel counts multiples of a 64-byte chunk, tensors
+ * below 2 GiB, pixel count a multiple of the chunk); otherwise use the functions above.
+ * uh_convt2x2_pack: reference weight [Cin][Cout][2][2] fp32 -> w_fwd [(q,co)][ci] and w_dgrad [ci][(q,co)]
+ * (Cin*Cout*4 elements each, activation dtype), q = 2*r + s. */
+int uh_convt2x2_mfma_ok(int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int dt);
+int uh_convt2x2_pack(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
+int uh_convt2x2_fwd_mfma(const void* x, int ldx, const void* w_fwd, const float* bias, void* y, int ldy,
+                         int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int pad_top, int pad_left,
+                         int dt, uh_stream stream);
+int uh_convt2x2_dgrad_mfma(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx,
+                           int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int pad_top, int pad_left,
+                           int dt, uh_stream stream);
+size_t uh_convt2x2_wgrad_mfma_ws_bytes(int B, int h, int w_, int Cin, int Cout, int dt);
+int uh_convt2x2_wgrad_mfma(const void* dy, int lddy, const void* x, int ldx, float* dw, float* dbias,
+                           void* ws, size_t ws_bytes, int B, int h, int w_, int Cin, int Cout,
+                           int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
 
 /* ---- OutConv: nn.Conv2d(Cin, ncls, 1) with bias  (unet_parts.py:103) -----------------------
  * w [ncls][Cin] fp32, bias [ncls] fp32; logits are fp32 [npix][ncls]. */

@@ -203,7 +203,10 @@ def test_outconv_1x1(dtype, ncls):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,h,w,Cin,Ho,Wo", [(2, 8, 8, 64, 16, 16), (2, 8, 9, 16, 17, 19), (1, 4, 4, 128, 8, 8)])
+@pytest.mark.parametrize("B,h,w,Cin,Ho,Wo", [(2, 8, 8, 64, 16, 16), (2, 8, 9, 16, 17, 19), (1, 4, 4, 128, 8, 8),
+                                             # MFMA GEMM path (csrc/convt_mfma.hip): exact / padded / partial tiles / deep K
+                                             (2, 16, 16, 128, 32, 32), (1, 32, 32, 64, 64, 64), (2, 8, 8, 64, 17, 19),
+                                             (4, 32, 32, 256, 64, 64), (2, 16, 24, 512, 32, 48), (3, 8, 12, 192, 16, 24)])
 def test_conv_transpose_pad(dtype, B, h, w, Cin, Ho, Wo):
     from unet_amd import ops
     dev = _dev()
@@ -213,8 +216,8 @@ def test_conv_transpose_pad(dtype, B, h, w, Cin, Ho, Wo):
     wt = torch.randn(Cin, Cout, 2, 2, generator=g) / (Cin ** 0.5)
     bias = torch.randn(Cout, generator=g)
     cot = torch.randn(B, Cout, Ho, Wo, generator=g)
-    if dtype == torch.bfloat16:
-        x, cot = x.bfloat16().float(), cot.bfloat16().float()
+    if dtype == torch.bfloat16:          # like with like: the MFMA path multiplies bf16 weights (what autocast does too)
+        x, cot, wt = x.bfloat16().float(), cot.bfloat16().float(), wt.bfloat16().float()
     xd, wd, bd = x.double().requires_grad_(True), wt.double().requires_grad_(True), bias.double().requires_grad_(True)
     up = F.conv_transpose2d(xd, wd, bd, stride=2)
     dY, dX = Ho - up.shape[2], Wo - up.shape[3]

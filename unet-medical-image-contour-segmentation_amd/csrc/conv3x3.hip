@@ -67,44 +67,69 @@ extern "C" int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, 
 }
 
 // All 3x3 filters of a model in ONE launch (the per-layer form costs ~10 us of launch + tail per layer, 18 layers per
-// step).  table[l] = {w pointer, sO, sI, sH, sW, Cout, Cin, first element of layer l in the flat outputs}.
+// step).  table[l] = {w pointer, sO, sI, sH, sW, Cout, Cin, first element of layer l in the flat outputs, first TILE of
+// layer l, 0}.  Workgroup = one 32(o) x 32(i) tile of one tap, transposed through LDS so that BOTH packed copies are
+// written in 64-byte runs (the backward-data copy [i][tap'][o] is a transpose of the forward copy [o][tap][i]; written
+// straight from registers it would be 2-byte stores 9*Cout elements apart).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_w3x3_batched_kernel(const long long* __restrict__ table, int nlayers,
-                                                                long long total, T* __restrict__ wf, T* __restrict__ wd) {
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        int lo = 0, hi = nlayers - 1;                 // last layer whose first element <= idx
+                                                                long long ntiles, T* __restrict__ wf, T* __restrict__ wd) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        int lo = 0, hi = nlayers - 1;                 // last layer whose first tile <= tl
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (table[mid * 8 + 7] <= idx) lo = mid; else hi = mid - 1;
+            if (table[mid * 10 + 8] <= tl) lo = mid; else hi = mid - 1;
         }
-        const long long* e = table + lo * 8;
+        const long long* e = table + lo * 10;
         const float* w = reinterpret_cast<const float*>(e[0]);
         const long long sO = e[1], sI = e[2], sH = e[3], sW = e[4];
         const int Cout = (int)e[5], Cin = (int)e[6];
-        const long long base = e[7], k = idx - base;
-        const int i = (int)(k % Cin);
-        const int t = (int)((k / Cin) % 9);
-        const int o = (int)(k / (9 * (long long)Cin));
+        const long long base = e[7];
+        const int ti = (Cin + 31) >> 5, to = (Cout + 31) >> 5;
+        long long k = tl - e[8];
+        const int it = (int)(k % ti); k /= ti;
+        const int ot = (int)(k % to);
+        const int t = (int)(k / to);                   // tap 0..8
         const int r = t / 3, s_ = t - 3 * r;
-        const float v = w[o * sO + i * sI + r * sH + s_ * sW];
-        wf[idx] = uh_from_f32<T>(v);
-        if (wd) wd[base + (((long long)i * 3 + (2 - r)) * 3 + (2 - s_)) * Cout + o] = uh_from_f32<T>(v);
+        const int o0 = ot * 32, i0 = it * 32;
+        __syncthreads();                               // the previous tile's readers are done
+#pragma unroll
+        for (int rr = ty; rr < 32; rr += 8) {
+            const int o = o0 + rr, i = i0 + tx;
+            float v = 0.f;
+            if (o < Cout && i < Cin) {
+                v = w[o * sO + i * sI + r * sH + s_ * sW];
+                wf[base + ((long long)o * 9 + t) * Cin + i] = uh_from_f32<T>(v);
+            }
+            tile[rr][tx] = v;
+        }
+        __syncthreads();
+        if (wd) {
+            const int td = (2 - r) * 3 + (2 - s_);
+#pragma unroll
+            for (int rr = ty; rr < 32; rr += 8) {
+                const int i = i0 + rr, o = o0 + tx;
+                if (i < Cin && o < Cout) wd[base + ((long long)i * 9 + td) * Cout + o] = uh_from_f32<T>(tile[tx][rr]);
+            }
+        }
     }
 }
 
-extern "C" int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t total, void* w_fwd_flat, void* w_dgrad_flat,
+extern "C" int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t ntiles, void* w_fwd_flat, void* w_dgrad_flat,
                                     int dt, uh_stream stream) {
-    UH_REQUIRE(table && w_fwd_flat && nlayers > 0 && total > 0, "uh_pack_w3x3_batched: bad arguments");
+    UH_REQUIRE(table && w_fwd_flat && nlayers > 0 && ntiles > 0, "uh_pack_w3x3_batched: bad arguments");
     UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_pack_w3x3_batched: bad dtype %d", dt);
-    int64_t g = (total + 255) / 256;
-    if (g > 256 * 32) g = 256 * 32;
+    int64_t g = ntiles;
+    if (g > 256 * 64) g = 256 * 64;
     hipStream_t st = (hipStream_t)stream;
     if (dt == UH_BF16)
         hipLaunchKernelGGL(pack_w3x3_batched_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, st, (const long long*)table,
-                           nlayers, (long long)total, (bf16_t*)w_fwd_flat, (bf16_t*)w_dgrad_flat);
+                           nlayers, (long long)ntiles, (bf16_t*)w_fwd_flat, (bf16_t*)w_dgrad_flat);
     else
         hipLaunchKernelGGL(pack_w3x3_batched_kernel<float>, dim3((unsigned)g), dim3(256), 0, st, (const long long*)table,
-                           nlayers, (long long)total, (float*)w_fwd_flat, (float*)w_dgrad_flat);
+                           nlayers, (long long)ntiles, (float*)w_fwd_flat, (float*)w_dgrad_flat);
     UH_CHECK_LAUNCH("uh_pack_w3x3_batched");
     return UH_OK;
 }

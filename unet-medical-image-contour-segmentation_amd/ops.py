@@ -191,15 +191,17 @@ class ConvWeightPack:
 
     def _build(self):
         dev = self.weights[0].device
-        rows, off = [], 0
+        rows, off, toff = [], 0, 0
         self.offsets = []
         for w in self.weights:
             O, I = w.shape[0], w.shape[1]
             sO, sI, sH, sW = w.stride()
-            rows.append([w.data_ptr(), sO, sI, sH, sW, O, I, off])
+            rows.append([w.data_ptr(), sO, sI, sH, sW, O, I, off, toff, 0])
             self.offsets.append(off)
             off += O * 9 * I
+            toff += ((O + 31) // 32) * ((I + 31) // 32) * 9
         self.total = off
+        self.ntiles = toff
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.ptrs = [w.data_ptr() for w in self.weights]
         self.strides = [tuple(w.stride()) for w in self.weights]
@@ -211,7 +213,7 @@ class ConvWeightPack:
     def refresh(self):
         if any(w.data_ptr() != p or tuple(w.stride()) != st for w, p, st in zip(self.weights, self.ptrs, self.strides)):
             self._build()                       # a parameter was re-allocated (.to(), load with assign=True, ...)
-        LIB.call("uh_pack_w3x3_batched", self.table.data_ptr(), len(self.weights), self.total, self.wf.data_ptr(),
+        LIB.call("uh_pack_w3x3_batched", self.table.data_ptr(), len(self.weights), self.ntiles, self.wf.data_ptr(),
                  self.wd.data_ptr(), UH_BF16 if self.dtype == torch.bfloat16 else UH_F32, _stream())
         self.versions = [w._version for w in self.weights]
         self.epoch = WEIGHT_EPOCH
@@ -534,7 +536,8 @@ class UpsampleBilinearPadFn(Function):
 
 
 class ConvTranspose2x2PadFn(Function):
-    """nn.ConvTranspose2d(Cin, Cin//2, 2, stride=2) + F.pad (unet_parts.py:73,85-88)."""
+    """nn.ConvTranspose2d(Cin, Cin//2, 2, stride=2) + F.pad (unet_parts.py:73,85-88).  MFMA GEMMs over pixels
+    (csrc/convt_mfma.hip) when the shape qualifies, else the LDS-tiled SIMT kernels of csrc/convt_1x1.hip."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, Ho: int, Wo: int):
@@ -546,29 +549,54 @@ class ConvTranspose2x2PadFn(Function):
         bc = bias.contiguous().float()
         pt, pl = _pad_geometry(h, w, Ho, Wo)
         y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
-        LIB.call("uh_convt2x2_fwd", x.data_ptr(), pixel_ld(x), wc.data_ptr(), bc.data_ptr(), y.data_ptr(), Cout,
-                 B, h, w, Cin, Cout, Ho, Wo, pt, pl, _dt(x), _stream())
-        ctx.save_for_backward(x, wc)
+        dt = _dt(x)
+        mfma = bool(LIB.query("uh_convt2x2_mfma_ok", B, h, w, Cin, Cout, Ho, Wo, dt))
+        wd = None
+        if mfma:
+            wf = torch.empty(Cin * Cout * 4, dtype=x.dtype, device=x.device)
+            wd = torch.empty(Cin * Cout * 4, dtype=x.dtype, device=x.device)
+            LIB.call("uh_convt2x2_pack", wc.data_ptr(), Cin, Cout, wf.data_ptr(), wd.data_ptr(), dt, _stream())
+            with _Timed("convt2x2_fwd_mfma", 2.0 * B * h * w * Cin * 4 * Cout):
+                LIB.call("uh_convt2x2_fwd_mfma", x.data_ptr(), pixel_ld(x), wf.data_ptr(), bc.data_ptr(), y.data_ptr(), Cout,
+                         B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        else:
+            LIB.call("uh_convt2x2_fwd", x.data_ptr(), pixel_ld(x), wc.data_ptr(), bc.data_ptr(), y.data_ptr(), Cout,
+                     B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        ctx.save_for_backward(x, wc, wd)
         ctx.geom = (B, h, w, Cin, Cout, Ho, Wo, pt, pl)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wc = ctx.saved_tensors
+        x, wc, wd = ctx.saved_tensors
         B, h, w, Cin, Cout, Ho, Wo, pt, pl = ctx.geom
         dy = dense_nhwc(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dt = _dt(x)
+        mfma = wd is not None
+        flops = 2.0 * B * h * w * Cin * 4 * Cout
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, h, w, Cin), dtype=x.dtype, device=x.device)
-            LIB.call("uh_convt2x2_dgrad", dy.data_ptr(), pixel_ld(dy), wc.data_ptr(), dx.data_ptr(), Cin, B, h, w,
-                     Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
-        nbytes = LIB.query("uh_convt2x2_wgrad_ws_bytes", B, h, w, Cin, Cout)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            if mfma:
+                with _Timed("convt2x2_dgrad_mfma", flops):
+                    LIB.call("uh_convt2x2_dgrad_mfma", dy.data_ptr(), pixel_ld(dy), wd.data_ptr(), dx.data_ptr(), Cin, B, h, w,
+                             Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+            else:
+                LIB.call("uh_convt2x2_dgrad", dy.data_ptr(), pixel_ld(dy), wc.data_ptr(), dx.data_ptr(), Cin, B, h, w,
+                         Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
         dw = torch.empty((Cin, Cout, 2, 2), dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
-        LIB.call("uh_convt2x2_wgrad", dy.data_ptr(), pixel_ld(dy), x.data_ptr(), pixel_ld(x), dw.data_ptr(),
-                 db.data_ptr(), ws.data_ptr(), nbytes, B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        if mfma:
+            nbytes = LIB.query("uh_convt2x2_wgrad_mfma_ws_bytes", B, h, w, Cin, Cout, dt)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            with _Timed("convt2x2_wgrad_mfma", flops):
+                LIB.call("uh_convt2x2_wgrad_mfma", dy.data_ptr(), pixel_ld(dy), x.data_ptr(), pixel_ld(x), dw.data_ptr(),
+                         db.data_ptr(), ws.data_ptr(), nbytes, B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
+        else:
+            nbytes = LIB.query("uh_convt2x2_wgrad_ws_bytes", B, h, w, Cin, Cout)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            LIB.call("uh_convt2x2_wgrad", dy.data_ptr(), pixel_ld(dy), x.data_ptr(), pixel_ld(x), dw.data_ptr(),
+                     db.data_ptr(), ws.data_ptr(), nbytes, B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
         return dx, dw, db, None, None
 
 
