@@ -214,6 +214,22 @@ def main():
                                              (MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS), 4),
             "roofline": roof, "kernels": kernels,
         }
+        if world == 1:
+            # forward-only inference (model.eval(): running statistics folded into the conv epilogue)
+            model.eval()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                for _ in range(3):
+                    model(images)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    logits = model(images)
+                e1.record()
+                torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            out["inference"] = {"images_per_sec": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "batch": B,
+                                "what": "eval-mode forward, fused conv+BN(running stats)+ReLU kernels, logits only"}
+            model.train()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
             out["cpu_baseline"]["dice_vs_ref"] = dice_vs_ref()
