@@ -324,3 +324,38 @@ if __name__ == "__main__":
     g10_eval()
     g11_depth5()
     g9_full_unet()
+    g12_data_loading()
+
+
+def g12_data_loading():
+    """utils/data_loading.py: three synthetic grey images + {0,128,255} masks written as PNG, read back through the
+    reference's BasicDataset (augment on, scale 1.0 and 0.5).  Stores the raw arrays and every item."""
+    import tempfile
+    from PIL import Image
+    from utils.data_loading import BasicDataset
+    rng = np.random.default_rng(12)
+    rec = {}
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "imgs")); os.makedirs(os.path.join(d, "masks"))
+        names = ["a01", "b02", "c03"]
+        for k, n in enumerate(names):
+            h, w = 20 + 2 * k, 24 + 4 * k
+            img = (rng.random((h, w)) * 255).astype(np.uint8)
+            mask = rng.choice(np.array([0, 128, 255], np.uint8), size=(h, w), p=[0.2, 0.5, 0.3])
+            Image.fromarray(img, mode="L").save(os.path.join(d, "imgs", n + ".png"))
+            Image.fromarray(mask, mode="L").save(os.path.join(d, "masks", n + "_mask.png"))
+            rec[f"raw.{n}.img"], rec[f"raw.{n}.mask"] = img, mask
+        for scale in (1.0, 0.5):
+            ds = BasicDataset(os.path.join(d, "imgs"), os.path.join(d, "masks"), scale, augment=True)
+            order = list(ds.ids)
+            rec[f"s{scale}.len"] = np.array(len(ds))
+            rec[f"s{scale}.mask_values"] = np.array(ds.mask_values)
+            for name in names:
+                base = order.index(name) * 4
+                for r in range(4):
+                    it = ds[base + r]
+                    rec[f"s{scale}.{name}.r{r}.image"] = npy(it["image"])
+                    rec[f"s{scale}.{name}.r{r}.mask"] = npy(it["mask"])
+        ds = BasicDataset(os.path.join(d, "imgs"), os.path.join(d, "masks"), 1.0, augment=False)
+        rec["noaug.len"] = np.array(len(ds))
+    save("g12_data_loading", **rec)

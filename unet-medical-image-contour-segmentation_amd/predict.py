@@ -17,23 +17,14 @@ from . import ops
 
 
 def preprocess_image(pil_img, scale: float = 1.0) -> np.ndarray:
-    """Image branch of BasicDataset.preprocess (data_loading.py:65-91): BICUBIC resize by `scale`, HW -> 1HW /
-    HWC -> CHW, divide by 255 when any value exceeds 1."""
-    if hasattr(pil_img, "size") and hasattr(pil_img, "resize") and not isinstance(pil_img, np.ndarray):
-        from PIL import Image
-        w, h = pil_img.size
-        new_w, new_h = int(scale * w), int(scale * h)
-        assert new_w > 0 and new_h > 0, "Scale is too small, resized images would have no pixel"
-        pil_img = pil_img.resize((new_w, new_h), resample=Image.BICUBIC)
-        img = np.asarray(pil_img)
-    else:
-        img = np.asarray(pil_img)
+    """Image branch of BasicDataset.preprocess (data_loading.py:65-91); ndarrays are taken as already-decoded images."""
+    from .utils.data_loading import BasicDataset
+    if isinstance(pil_img, np.ndarray):
         if scale != 1.0:
             raise ValueError("scale != 1 needs a PIL image")
-    img = img[np.newaxis, ...] if img.ndim == 2 else img.transpose((2, 0, 1))
-    if (img > 1).any():
-        img = img.astype(np.float32) / 255.0
-    return img
+        img = pil_img[np.newaxis, ...] if pil_img.ndim == 2 else pil_img.transpose((2, 0, 1))
+        return img.astype(np.float32) / 255.0 if (img > 1).any() else img
+    return BasicDataset.preprocess(None, pil_img, scale, is_mask=False)
 
 
 def predict_img(model, full_img, device):
