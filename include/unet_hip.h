@@ -233,6 +233,14 @@ int uh_cc_loss_host(const uint8_t* masks, int B, int H, int W, int edge_distance
 int uh_argmax_classes(const float* logits, int64_t npix, int ncls, int64_t* out, uh_stream stream);
 int uh_threshold_mask(const float* logits, int64_t n, float* out, uh_stream stream);
 
+/* ---- mask post-processing on the device  (utils/post_process.py:51-88, used by evaluate.py:71-78) ----
+ * mask / out: DEVICE uint8 [B][H][W] class indices {0,1,2}.  Hole filling of the class-2 foreground, k x k opening,
+ * 8-connected components with fewer than min_area pixels removed; out is 2 for kept pixels and 0 elsewhere (the
+ * reference zeroes the class-1 background too).  ws: uh_postprocess_ws_bytes() bytes.  PARITY UNPINNED (OpenCV). */
+size_t uh_postprocess_ws_bytes(int B, int H, int W);
+int uh_postprocess_masks(const uint8_t* mask, uint8_t* out, int B, int H, int W, int min_area,
+                         int morph_kernel_size, void* ws, size_t ws_bytes, uh_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

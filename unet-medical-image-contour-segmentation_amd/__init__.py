@@ -10,3 +10,4 @@ from .predict import predict_img, mask_to_image, preprocess_image  # noqa: F401
 from .checkpoint import save_checkpoint, load_checkpoint  # noqa: F401
 from .synthetic import ellipse_batch  # noqa: F401
 from .utils.data_loading import BasicDataset, CarvanaDataset, load_image  # noqa: F401
+from .utils.post_process import postprocess_mask, remove_internal_regions  # noqa: F401

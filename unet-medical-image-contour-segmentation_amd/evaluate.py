@@ -1,21 +1,23 @@
-"""Validation metric of /root/reference/evaluate.py:12-171 (raw Dice; the OpenCV post-processing
-branch and PNG dumps are host-side and outside the hot-path scope)."""
+"""Validation metric of /root/reference/evaluate.py:12-171: eval-mode forward (running statistics folded into the conv
+epilogue), device-side masks, raw Dice and -- with postprocess=True -- the Dice after utils/post_process.postprocess_mask,
+which here runs on the device for the whole batch (the reference copies every image to the host for OpenCV).  PNG dumps
+(epoch_pred_dir) are host-side file output and are not written."""
 from __future__ import annotations
 
 import torch
 
 from . import ops
 from .utils.dice_score import dice_coeff
+from .utils.post_process import postprocess_mask
 
 
 @torch.inference_mode()
 def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=False):
-    if postprocess:
-        raise NotImplementedError("OpenCV post-processing (utils/post_process.py) is out of scope; pass postprocess=False")
     net.eval()
     batches = list(dataloader)
     num_val_batches = len(batches)
     dice_score = 0
+    dice_post = 0
     min_dice = 10
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         for batch in batches:
@@ -28,12 +30,28 @@ def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=Fals
                 assert mask_true.min() >= 0 and mask_true.max() <= 1, "True mask indices should be in [0, 1]"
                 pred = ops.threshold_mask(mask_pred.squeeze(1))    # sigmoid(x) > 0.5  <=>  x > 0   (evaluate.py:60-62)
                 d = dice_coeff(pred, mask_true, reduce_batch_first=False)
+                cur = d
+                if postprocess:
+                    # evaluate.py:71-78 literally: the binary mask goes in coded {0,255}, postprocess_mask looks for class 2
+                    # (finds none) and `processed // 255` is the prediction that is scored
+                    coded = (pred * 255).to(torch.uint8)
+                    processed = (postprocess_mask(coded) // 255).float()
+                    dp = dice_coeff(processed, mask_true, reduce_batch_first=False)
+                    dice_post += dp
+                    cur = torch.minimum(d, dp)                                                  # evaluate.py:85
             else:
                 idx = ops.argmax_classes(mask_pred)                                             # evaluate.py:111
-                d = dice_coeff((idx == 2).float(), (mask_true == 2).float(), reduce_batch_first=False)
+                true_c = (mask_true == 2).float()
+                d = dice_coeff((idx == 2).float(), true_c, reduce_batch_first=False)
+                cur = d
+                if postprocess:
+                    processed = postprocess_mask(idx.to(torch.uint8))                           # evaluate.py:125-134
+                    dice_post += dice_coeff((processed == 2).float(), true_c, reduce_batch_first=False)
             dice_score += d
-            if d < min_dice:
-                min_dice = d
+            if cur < min_dice:
+                min_dice = cur
     net.train()
     n = max(num_val_batches, 1)
-    return dice_score / n, dice_score / n, min_dice
+    if not postprocess:
+        dice_post = dice_score                                                                  # evaluate.py:168-169
+    return dice_score / n, dice_post / n, min_dice
