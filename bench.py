@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity path) instead of bf16")
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -129,12 +131,21 @@ def main():
 
     bilinear = not args.convt
     torch.manual_seed(0)
-    model = unet_amd.UNet(1, 1, bilinear=bilinear).to(memory_format=torch.channels_last).to(dev)
+    n_in, n_cls = 1, 1
+    if args.config4:
+        n_in, n_cls = 3, 4
+        if args.size == 512:
+            args.size = 1024
+        model = unet_amd.UNetDepth(3, 4, True, widths=(64, 128, 256, 512, 1024, 2048))
+        TRAIN_GFLOP_PER_IMAGE[True] = 4767.0 * (args.size / 1024.0) ** 2          # 1589 GFLOP fwd per 3x1024^2 image
+    else:
+        model = unet_amd.UNet(1, 1, bilinear=bilinear)
+    model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
     stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream)
     g = torch.Generator().manual_seed(1 + rank)
     B, S = args.batch, args.size
-    images = torch.rand(B, 1, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    images = torch.rand(B, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     masks = torch.randint(0, 3, (B, S, S), generator=g).to(dev)
 
     def barrier():
@@ -200,12 +211,13 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / elapsed
         out = {
-            "metric": "images/sec (train step) UNet 1x512x512->1",
+            "metric": f"images/sec (train step) UNet {n_in}x{S}x{S}->{n_cls}",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
-            "config": {"workload": f"UNet(1,1,bilinear={bilinear}) train step (BCE+Dice+0.25*boundary, clip 1.0, RMSprop), "
-                                   f"{B} x 1x{S}x{S} per GPU, global batch {B * world}",
+            "config": {"workload": (f"UNet({n_in},{n_cls},bilinear={bilinear}{', depth 5' if args.config4 else ''}) train step "
+                                    f"({'BCE' if n_cls == 1 else 'CE'}+Dice+boundary, clip 1.0, RMSprop), "
+                                    f"{B} x {n_in}x{S}x{S} per GPU, global batch {B * world}"),
                        "parallelism": f"dp{world}", "global_batch": B * world, "per_gpu_batch": B,
                        "bn": "per-rank batch statistics", "dice": "global-batch sums (all-reduced)"},
             "loss": round(loss, 6),
