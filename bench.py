@@ -75,7 +75,7 @@ def cpu_baseline(size: int):
                       f"1 warm-up + best of {nsteps} steps ({best:.2f} s/step)"}
 
 
-def dice_vs_ref(steps: int = 120, size: int = 64, batch: int = 4, lr: float = 1e-4):
+def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4):
     """BASELINE metric's second half, "Dice vs ref": the same `steps` train steps of UNet_T(1,1,bilinear) on seeded
     synthetic ellipse batches run by the CPU oracle (reference restatement) and by the HIP path (fp32 and bf16), then the
     evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here)."""

@@ -11,3 +11,4 @@ from .checkpoint import save_checkpoint, load_checkpoint  # noqa: F401
 from .synthetic import ellipse_batch  # noqa: F401
 from .utils.data_loading import BasicDataset, CarvanaDataset, load_image  # noqa: F401
 from .utils.post_process import postprocess_mask, remove_internal_regions  # noqa: F401
+from .inference import GraphedForward  # noqa: F401

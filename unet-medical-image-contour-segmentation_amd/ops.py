@@ -167,7 +167,11 @@ WEIGHT_EPOCH = 0
 
 def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """KRSC filter pack for the inference forward, cached on the parameter until it changes."""
-    key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, dtype, tuple(weight.stride()))
+    try:
+        version = weight._version
+    except RuntimeError:                      # a temporary created under torch.inference_mode (zero-padded small-width filter)
+        return pack_w3x3(weight, dtype, False)[0]
+    key = (weight.data_ptr(), version, WEIGHT_EPOCH, dtype, tuple(weight.stride()))
     hit = getattr(weight, "_uh_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]

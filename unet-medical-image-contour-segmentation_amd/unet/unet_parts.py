@@ -22,10 +22,60 @@ import torch.nn as nn
 from .. import ops
 
 
-def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool):
+CPAD = 64          # channel granularity of the MFMA conv kernels (64-channel slabs, 64-byte K chunks)
+
+
+def _rup(c: int) -> int:
+    return (c + CPAD - 1) // CPAD * CPAD
+
+
+def _pad_c(t, cpad: int):
+    """Zero-pad the channel (last) axis of an NHWC tensor up to `cpad` (differentiable torch plumbing)."""
+    c = t.shape[-1]
+    return t if c == cpad else torch.nn.functional.pad(t, (0, cpad - c))
+
+
+def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, keep_padded: bool = False,
+                  x0_channels: int = None):
+    """One (conv3x3 -> BatchNorm -> ReLU) layer.  Layers whose channel counts are not multiples of 64 (the small-width
+    UNet_S / UNet_T of unet_model.py:52-126) are run as the next larger 64-aligned layer with zero filters / unit gamma
+    in the padding, so that they use the same MFMA kernels as the full-width UNet instead of the generic scalar
+    kernels: padded input channels meet zero filter taps, padded output channels are exactly 0 before and after
+    BatchNorm+ReLU (mean 0, shift 0), and their gradients never reach a parameter (the slices below drop them).
+    `x0_channels`: x0 is already such a padded tensor and only its first x0_channels channels are real.
+    `keep_padded`: return the padded tensor (DoubleConv hands it to its second conv without a copy)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return ops.ConvBnReluFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, training, momentum, bn.eps)
+    w = conv.weight
+    Cout, Cin = w.shape[0], w.shape[1]
+    C0 = x0_channels if x0_channels is not None else x0.shape[-1]
+    C1 = 0 if x1 is None else x1.shape[-1]
+    stem = Cin <= 4 and x1 is None and x0_channels is None      # the stem kernels take any Cin <= 4 but want 64 outputs
+    Cp0 = C0 if stem else (x0.shape[-1] if x0_channels is not None else _rup(C0))
+    Cp1 = _rup(C1) if C1 else 0
+    Cop = _rup(Cout)
+    if Cp0 == C0 and Cp1 == C1 and Cop == Cout and x0_channels is None:
+        z = ops.ConvBnReluFn.apply(x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, training, momentum, bn.eps)
+        return z
+    x0p = x0 if x0_channels is not None else _pad_c(x0, Cp0)
+    x1p = None if x1 is None else _pad_c(x1, Cp1)
+    # filter [Cout, C0 + C1, 3, 3] -> [Cop, Cp0 + Cp1, 3, 3]: each source's channel block is padded separately
+    wp = torch.nn.functional.pad(w[:, :C0], (0, 0, 0, 0, 0, Cp0 - C0))
+    if C1:
+        wp = torch.cat([wp, torch.nn.functional.pad(w[:, C0:], (0, 0, 0, 0, 0, Cp1 - C1))], dim=1)
+    wp = torch.nn.functional.pad(wp, (0, 0, 0, 0, 0, 0, 0, Cop - Cout))
+    gp = torch.nn.functional.pad(bn.weight, (0, Cop - Cout), value=1.0)
+    bp = torch.nn.functional.pad(bn.bias, (0, Cop - Cout))
+    rm = rv = None
+    if bn.running_mean is not None:
+        rm = torch.nn.functional.pad(bn.running_mean, (0, Cop - Cout))
+        rv = torch.nn.functional.pad(bn.running_var, (0, Cop - Cout), value=1.0)
+    zp = ops.ConvBnReluFn.apply(x0p, x1p, wp, gp, bp, rm, rv, bn.num_batches_tracked, training, momentum, bn.eps)
+    if training and rm is not None:
+        with torch.no_grad():
+            bn.running_mean.copy_(rm[:Cout])
+            bn.running_var.copy_(rv[:Cout])
+    return zp if keep_padded else zp[..., :Cout]
 
 
 class DoubleConv(nn.Module):
@@ -47,8 +97,9 @@ class DoubleConv(nn.Module):
 
     def nhwc(self, x0, x1=None):
         seq = self.double_conv
-        h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training)
-        return _conv_bn_relu(h, None, seq[3], seq[4], self.training)
+        mid = seq[0].weight.shape[0]
+        h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training, keep_padded=True)
+        return _conv_bn_relu(h, None, seq[3], seq[4], self.training, x0_channels=mid if h.shape[-1] != mid else None)
 
     def forward(self, x):
         return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
