@@ -1694,12 +1694,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v2(const T* __restrict
 }
 
 // ---- stem wgrad v3 (Cin <= 4, Cout == 64): persistent workgroups over 16x16 tiles, x halo in LDS, thread = (pixel lane
-// of 32, 8 output channels) with 9*Cin*8 accumulators in registers; one slab per workgroup.
+// of 32, 8 output channels) with 9*CIN*8 accumulators in registers; one slab per workgroup.  CIN is the number of input
+// channels ONE workgroup handles (1 keeps the 72 accumulators in registers); blockIdx.y selects the input channel
+// `ci0 = blockIdx.y * CIN` of the cin_total the layer has, so Cin = 2..4 re-reads dy per channel instead of spilling.
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict__ dy, int lddy, const T* __restrict__ x,
                                                              int ldx, float* __restrict__ slabs, int B, int H, int W,
-                                                             int tilesX, int tilesY) {
+                                                             int tilesX, int tilesY, int cin_total) {
     constexpr int V = 8, COUT = 64;
+    const int ci0 = blockIdx.y * CIN;
     __shared__ float xs[HALO_PIX * CIN];
     __shared__ float red[4][9 * CIN][COUT];
     const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;
@@ -1722,7 +1725,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict
             int hy = q / HALO_W, hx = q - hy * HALO_W;
             int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
             float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci0 + ci]);
             xs[idx] = v;
         }
         __syncthreads();
@@ -1761,11 +1764,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict
             for (int i = 0; i < V; ++i) red[tid >> 6][k][g * V + i] = acc[k][i];
     }
     __syncthreads();
-    float* slab = slabs + (int64_t)blockIdx.x * COUT * 9 * CIN;
+    float* slab = slabs + (int64_t)blockIdx.x * COUT * 9 * cin_total;
     for (int idx = tid; idx < 9 * CIN * COUT; idx += 256) {
         const int k = idx / COUT, c = idx - k * COUT;
         // slab layout [co][tap][ci]
-        slab[((int64_t)c * 9 + k / CIN) * CIN + (k % CIN)] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+        slab[((int64_t)c * 9 + k / CIN) * cin_total + ci0 + (k % CIN)] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
     }
 }
 
@@ -1888,9 +1891,9 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         constexpr int V = 16 / ES;
         bool done = false;
         if constexpr (ES == 2) {
-            if (Cin == 1 && Cout == 64 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {      // 72 accumulators per lane
-                hipLaunchKernelGGL((conv3x3_wgrad_stem_v3<T, 1>), dim3(p.nsplit), dim3(256), 0, st, dy, lddy, x0, ld0, slabs, B,
-                                   H, W, p.tilesX, p.tilesY);
+            if (Cin <= 4 && Cout == 64 && uh_aligned16(dy) && (lddy * ES) % 16 == 0) {      // 72 accumulators per lane
+                hipLaunchKernelGGL((conv3x3_wgrad_stem_v3<T, 1>), dim3(p.nsplit, Cin), dim3(256), 0, st, dy, lddy, x0, ld0, slabs,
+                                   B, H, W, p.tilesX, p.tilesY, Cin);
                 UH_CHECK_LAUNCH("conv3x3_wgrad_stem_v3");
                 done = true;
             }
