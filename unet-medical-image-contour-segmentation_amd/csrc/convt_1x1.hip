@@ -230,7 +230,7 @@ extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ld
         CtWgrad<T> f{(const T*)x, ldx, (const T*)dy, lddy, (float*)ws, g};
         hipLaunchKernelGGL(ct_gemm_kernel<CtWgrad<T>>, dim3((Cin + 63) / 64, (4 * Cout + 63) / 64, nsplit), dim3(256), 0, st, f,
                            (int64_t)Cin, 4 * Cout, K, nsplit);
-        hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+        (void)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
         int slices = (int)((K * 4 + 1023) / 1024);
         if (slices > 512) slices = 512;
         if (slices < 1) slices = 1;

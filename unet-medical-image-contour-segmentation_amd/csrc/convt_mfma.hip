@@ -374,7 +374,7 @@ extern "C" int uh_convt2x2_fwd_mfma(const void* x, int ldx, const void* w_fwd, c
         UH_REQUIRE((ldx * (int)sizeof(T)) % 16 == 0 && (ldy * (int)sizeof(T)) % 8 == 0, "uh_convt2x2_fwd_mfma: strides");
         if (border) {
             UH_REQUIRE(ldy == Cout, "uh_convt2x2_fwd_mfma: a padded output must be pixel-dense");
-            hipMemsetAsync(y, 0, (size_t)B * Ho * Wo * Cout * sizeof(T), st);
+            (void)hipMemsetAsync(y, 0, (size_t)B * Ho * Wo * Cout * sizeof(T), st);
         }
         CtmArgs<T> a{};
         a.A = (const T*)w_fwd; a.lda = Cin; a.arows = 4 * Cout;
