@@ -193,9 +193,9 @@ extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, cons
 // Thread = (pixel lane, channel group of V).  Block = an interleaved set of 128-pixel chunks (blockIdx.x) x a slab of
 // up to 8 channel groups (blockIdx.y), so small feature maps with many channels still fill the chip.
 extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
-    // >= ~2048 workgroups over (pixel chunks) x (64-channel slabs) when the map is large enough
+    // >= ~4096 workgroups over (pixel chunks) x (64-channel slabs) when the map is large enough
     int64_t slabs = (C + 63) / 64;
-    int64_t cap = 2048 / slabs;
+    int64_t cap = 4096 / slabs;
     if (cap < 512) cap = 512;
     int64_t n = (npix + 127) / 128;
     if (n > cap) n = cap;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
         // Workgroups interleave over chunks of U*PL pixels (grid-stride): neighbouring workgroups stream neighbouring
         // addresses, so the concurrent streams spread over all HBM channels (one contiguous range per workgroup made
         // them march in lockstep at a 2^k stride).  U pixels per trip = 2U 16-byte loads in flight per lane.
-        constexpr int U = 4;
+        constexpr int U = 2;
         for (int64_t p = (int64_t)blockIdx.x * (U * PL) + pl; p < npix; p += (int64_t)gridDim.x * (U * PL)) {
             float d[U][V], yv[U][V];
 #pragma unroll
