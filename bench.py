@@ -41,6 +41,7 @@ def parse():
                     help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the forward-only inference timing (clean train-step profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank flow on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -226,7 +227,7 @@ def main():
                                              (MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS), 4),
             "roofline": roof, "kernels": kernels,
         }
-        if world == 1:
+        if world == 1 and not args.no_inference:
             # forward-only inference (model.eval(): running statistics folded into the conv epilogue)
             model.eval()
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):

@@ -193,9 +193,9 @@ extern "C" int uh_bn_relu_apply(const void* y, int ldy, const float* scale, cons
 // Thread = (pixel lane, channel group of V).  Block = an interleaved set of 128-pixel chunks (blockIdx.x) x a slab of
 // up to 8 channel groups (blockIdx.y), so small feature maps with many channels still fill the chip.
 extern "C" int uh_bn_bwd_nblk(int64_t npix, int C) {
-    // >= ~4096 workgroups over (pixel chunks) x (64-channel slabs) when the map is large enough
+    // >= ~2048 workgroups over (pixel chunks) x (64-channel slabs) when the map is large enough
     int64_t slabs = (C + 63) / 64;
-    int64_t cap = 4096 / slabs;
+    int64_t cap = 2048 / slabs;
     if (cap < 512) cap = 512;
     int64_t n = (npix + 127) / 128;
     if (n > cap) n = cap;
