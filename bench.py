@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity path) instead of bf16")
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
+    ap.add_argument("--cc-loss", action="store_true", help="add connected_component_loss to the loss value (config 5)")
     ap.add_argument("--config4", action="store_true",
                     help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,7 +144,7 @@ def main():
         model = unet_amd.UNet(1, 1, bilinear=bilinear)
     model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
-    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream, cc_loss=args.cc_loss)
     g = torch.Generator().manual_seed(1 + rank)
     B, S = args.batch, args.size
     images = torch.rand(B, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)

@@ -402,3 +402,42 @@ def test_dice_after_training_matches_oracle():
     assert r["ref_cpu_fp32"] > 0.9, r                      # the task is learned
     assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.03, r
     assert abs(r["hip_bf16"] - r["ref_cpu_fp32"]) < 0.06, r
+
+
+def test_cc_loss_option_adds_value_only():
+    """BASELINE config 5: connected_component_loss (train.py:124-132, commented out upstream) added to the loss VALUE; the
+    parameters after the step are identical with and without it (it carries no gradient)."""
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=9)
+    outs = []
+    for cc in (False, True):
+        torch.manual_seed(0)
+        model = unet_amd.UNet_T(1, 1, bilinear=False).to(dev)
+        st = unet_amd.TrainStepper(model, lr=1e-4, amp=False, cc_loss=cc)
+        t = st.step(im.to(dev), mk.to(dev))
+        torch.cuda.synchronize()
+        outs.append((float(t["loss"].detach()), float(t.get("cc", torch.zeros(()))), {k: v.clone() for k, v in model.state_dict().items()}))
+    assert outs[1][1] >= 0.0
+    assert abs(outs[1][0] - (outs[0][0] + outs[1][1])) < 1e-5
+    for k, v in outs[0][2].items():
+        assert torch.equal(v, outs[1][2][k]), k
+
+
+@pytest.mark.parametrize("ctor,bilinear,amp", [("UNet_T", True, False), ("UNet_T", False, False), ("UNet_S", False, True), ("UNet", True, True)])
+def test_train_step_is_bit_deterministic(ctor, bilinear, amp):
+    """No float atomics anywhere on the path: two runs of the same two steps give bit-identical logits, gradients and
+    parameters (split-K slabs, BatchNorm partial rows and Dice partials are all reduced in a fixed order)."""
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=9)
+    res = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        model = getattr(unet_amd, ctor)(1, 1, bilinear=bilinear).to(dev)
+        st = unet_amd.TrainStepper(model, lr=1e-4, amp=amp)
+        for _ in range(2):
+            t = st.step(im.to(dev), mk.to(dev))
+        torch.cuda.synchronize()
+        res.append((t["logits"].clone(), st.optimizer.flat_g.clone(), st.optimizer.flat_p.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v2(const T* __restrict__
                                                            int tilesY) {
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int PPT = 8;                       // pixels per thread per pass (256 px / 32 pixel lanes)
-    extern __shared__ float sm[];                // xs[324*4] | ws[9*4*CG] | red[4][CG]
+    extern __shared__ float sm[];                // xs[324*4] | ws[9*4*CG] | red[CG] | part[256][V]
     const int G = Cout / V;                      // channel groups
     const int GB = G < 8 ? G : 8;                // groups per pass (8 x V channels)
     const int CG = GB * V;
@@ -845,12 +845,20 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v2(const T* __restrict__
         if (stats) {
             // per-channel tile statistics: reduce over the pixel lanes (threads with equal g) through LDS
             for (int pass = 0; pass < 2; ++pass) {
+                // every thread parks its partial in LDS, then one thread per channel adds the pixel lanes in a FIXED
+                // order (no atomics: the statistics, and with them the whole step, must not depend on the schedule)
                 __syncthreads();
-                for (int idx = tid; idx < CG; idx += 256) red[idx] = 0.f;
-                __syncthreads();
-                if (pl < PL && cok) {
+                {
+                    float* part = red + CG;                       // [256][V]
 #pragma unroll
-                    for (int i = 0; i < V; ++i) atomicAdd(&red[g * V + i], s1[i]);      // LDS atomics, 32 adders per address
+                    for (int i = 0; i < V; ++i) part[tid * V + i] = (pl < PL && cok) ? s1[i] : 0.f;
+                    __syncthreads();
+                    for (int c = tid; c < CG; c += 256) {
+                        const int gg = c / V, ii = c - gg * V;
+                        float t = 0.f;
+                        for (int k = 0; k < PL; ++k) t += part[(k * GB + gg) * V + ii];
+                        red[c] = t;
+                    }
                 }
                 __syncthreads();
                 if (pass == 0) {
@@ -1137,7 +1145,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         }
         if (Cout % V == 0 && uh_aligned16(y) && (ldy * ES) % 16 == 0) {
             int G = Cout / V, GB = G < 8 ? G : 8, CG = GB * V;
-            size_t sm = (size_t)(HALO_PIX * 4 + 36 * CG + CG) * sizeof(float);
+            size_t sm = (size_t)(HALO_PIX * 4 + 36 * CG + CG + 256 * V) * sizeof(float);
             hipLaunchKernelGGL(conv3x3_fwd_stem_v2<T>, dim3(ntile), dim3(256), sm, st, x0, Cin, ld0, w, y, ldy, Cout, stats,
                                B, H, W, tilesX, tilesY);
             UH_CHECK_LAUNCH("conv3x3_fwd_stem_v2");

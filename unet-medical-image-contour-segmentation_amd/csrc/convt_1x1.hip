@@ -123,10 +123,10 @@ __global__ void ct_zero_kernel(T* y, int ldy, int64_t npix, int C) {
     y[(idx / C) * ldy + (idx % C)] = uh_from_f32<T>(0.f);
 }
 
-// dbias[o] += sum over the up-sampled region of dy[.., o]; grid = (64-channel slabs, pixel slices); one fp32 atomic
-// per (block, channel) into the zero-initialised dbias
+// dbias partials: sum over the up-sampled region of dy[.., o]; grid = (64-channel slabs, pixel slices); one partial row
+// per pixel slice (no atomics: the result must not depend on the schedule), summed in double by ct_dbias_finish_kernel
 template <typename T>
-__global__ __launch_bounds__(256) void ct_dbias_kernel(const T* __restrict__ dy, int lddy, CtGeom g, float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void ct_dbias_kernel(const T* __restrict__ dy, int lddy, CtGeom g, float* __restrict__ partials) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + cl;
@@ -143,7 +143,14 @@ __global__ __launch_bounds__(256) void ct_dbias_kernel(const T* __restrict__ dy,
         }
     red[sl][cl] = acc;
     __syncthreads();
-    if (sl == 0 && o < g.Cout) atomicAdd(&dbias[o], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    if (sl == 0 && o < g.Cout) partials[(int64_t)blockIdx.y * g.Cout + o] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void ct_dbias_finish_kernel(const float* __restrict__ partials, int nslice, int Cout, float* __restrict__ dbias) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= Cout) return;
+    double t = 0.0;
+    for (int k = 0; k < nslice; ++k) t += (double)partials[(int64_t)k * Cout + o];
+    dbias[o] = (float)t;
 }
 
 __global__ void convt_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t nw, int nsplit) {
@@ -208,8 +215,10 @@ static int convt_nsplit(int B, int h, int w_, int Cin, int Cout) {
     return want;
 }
 
+constexpr int CT_DBIAS_SLICES = 512;
 extern "C" size_t uh_convt2x2_wgrad_ws_bytes(int B, int h, int w_, int Cin, int Cout) {
-    return (size_t)convt_nsplit(B, h, w_, Cin, Cout) * ((size_t)Cin * Cout * 4) * sizeof(float) + 16;
+    return (size_t)convt_nsplit(B, h, w_, Cin, Cout) * ((size_t)Cin * Cout * 4) * sizeof(float) +
+           (size_t)CT_DBIAS_SLICES * Cout * sizeof(float) + 16;
 }
 
 extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, float* dbias, void* ws,
@@ -218,7 +227,7 @@ extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ld
     UH_REQUIRE(dy && x && dw && dbias && ws && B > 0 && h > 0 && w_ > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && ldx >= Cin,
                "uh_convt2x2_wgrad: bad args");
     int nsplit = convt_nsplit(B, h, w_, Cin, Cout);
-    size_t need = (size_t)nsplit * ((size_t)Cin * Cout * 4) * sizeof(float);
+    size_t need = (size_t)nsplit * ((size_t)Cin * Cout * 4) * sizeof(float) + (size_t)CT_DBIAS_SLICES * Cout * sizeof(float);
     if (ws_bytes < need) {
         uh_set_error("uh_convt2x2_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
         return UH_EWORKSPACE;
@@ -230,11 +239,13 @@ extern "C" int uh_convt2x2_wgrad(const void* dy, int lddy, const void* x, int ld
         CtWgrad<T> f{(const T*)x, ldx, (const T*)dy, lddy, (float*)ws, g};
         hipLaunchKernelGGL(ct_gemm_kernel<CtWgrad<T>>, dim3((Cin + 63) / 64, (4 * Cout + 63) / 64, nsplit), dim3(256), 0, st, f,
                            (int64_t)Cin, 4 * Cout, K, nsplit);
-        (void)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
         int slices = (int)((K * 4 + 1023) / 1024);
-        if (slices > 512) slices = 512;
+        if (slices > CT_DBIAS_SLICES) slices = CT_DBIAS_SLICES;
         if (slices < 1) slices = 1;
-        hipLaunchKernelGGL(ct_dbias_kernel<T>, dim3((Cout + 63) / 64, slices), dim3(256), 0, st, (const T*)dy, lddy, g, dbias);
+        float* partials = (float*)ws + (size_t)nsplit * ((size_t)Cin * Cout * 4);
+        hipLaunchKernelGGL(ct_dbias_kernel<T>, dim3((Cout + 63) / 64, slices), dim3(256), 0, st, (const T*)dy, lddy, g, partials);
+        hipLaunchKernelGGL(ct_dbias_finish_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st, (const float*)partials, slices, Cout,
+                           dbias);
     });
     UH_CHECK_LAUNCH("convt2x2_wgrad");
     int64_t nw = (int64_t)Cin * Cout * 4;

@@ -163,7 +163,7 @@ def _is_dense(p: torch.Tensor) -> bool:
 # ----------------------------------------------------------------------------------- one step
 def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: torch.Tensor, *, amp: bool = True,
                gradient_clipping: float = 1.0, reduce_sums=None, world: int = 1, check_nan: bool = True,
-               boundary_weight: Optional[float] = None) -> Dict[str, torch.Tensor]:
+               boundary_weight: Optional[float] = None, cc_loss: bool = False) -> Dict[str, torch.Tensor]:
     """Statement sequence of train.py:113-159.  `optimizer` is a FusedRMSprop (clipping fused into
     its step) or any torch.optim optimizer (then clip_grad_norm_ is applied as in the reference)."""
     assert images.shape[1] == model.n_channels, \
@@ -173,6 +173,15 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
         masks_pred = model(images)
         terms = seg_loss(masks_pred, true_masks, model.n_classes, reduce_sums=reduce_sums, world=world,
                          boundary_weight=boundary_weight)
+    if cc_loss and model.n_classes == 1:
+        # the block train.py:124-132 keeps commented out (BASELINE config 5 turns it on): a Python float, no gradient.
+        # sigmoid(x) > 0.5 <=> x > 0, so the 0/1 threshold mask stands in for the probabilities; like the reference this
+        # copies the batch's binary masks to the host and waits for them.
+        from .utils.connected_component_loss import connected_component_loss
+        cc = connected_component_loss(ops.threshold_mask(masks_pred.detach().squeeze(1)), edge_distance=50, min_area=1000,
+                                      penalty_weight=0.1)
+        terms["cc"] = torch.tensor(cc, device=masks_pred.device)
+        terms["loss"] = terms["loss"] + cc
     loss = terms["loss"]
     nan_host = nan_event = None
     if check_nan:
@@ -204,12 +213,13 @@ class TrainStepper:
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
                  gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
-                 wgrad_stream: bool = True):
+                 wgrad_stream: bool = True, cc_loss: bool = False):
         self.model = model
         if wgrad_stream and ops.WGRAD_STREAM is None:
             ops.WGRAD_STREAM = torch.cuda.Stream()
         self.amp = amp
         self.check_nan = check_nan
+        self.cc_loss = cc_loss
         self.group = process_group
         self.world = dpmod.world_size(process_group)
         self.reduce_sums = dpmod.make_sum_reducer(process_group)
@@ -228,7 +238,7 @@ class TrainStepper:
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
         return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
-                          reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan)
+                          reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan, cc_loss=self.cc_loss)
 
 
 # ----------------------------------------------------------------------------------- epoch loop
