@@ -441,3 +441,32 @@ def test_train_step_is_bit_deterministic(ctor, bilinear, amp):
         torch.cuda.synchronize()
         res.append((t["logits"].clone(), st.optimizer.flat_g.clone(), st.optimizer.flat_p.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("ctor,bilinear,amp", [("UNet_T", True, False), ("UNet_S", False, True)])
+def test_graph_captured_step_matches_eager(ctor, bilinear, amp):
+    """GraphedTrainStepper (the whole step replayed from a HIP graph) == TrainStepper, bit for bit, including the BatchNorm
+    buffers; the capture's warm-up steps must not count as training; a NaN batch raises and leaves the weights alone."""
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=4)
+    im2, mk2 = unet_amd.ellipse_batch(2, 64, seed=5)
+    res = []
+    for cls in (unet_amd.TrainStepper, unet_amd.GraphedTrainStepper):
+        torch.manual_seed(0)
+        model = getattr(unet_amd, ctor)(1, 1, bilinear=bilinear).to(dev)
+        st = cls(model, lr=1e-4, amp=amp)
+        for a, b in ((im, mk), (im2, mk2), (im, mk)):
+            t = st.step(a.to(dev), b.to(dev))
+        torch.cuda.synchronize()
+        res.append((float(t["loss"].detach()), {k: v.clone() for k, v in model.state_dict().items()}, st, model))
+    assert res[0][0] == res[1][0]
+    for k, v in res[0][1].items():
+        assert torch.equal(v, res[1][1][k]), k
+    st, model = res[1][2], res[1][3]
+    before = {k: v.clone() for k, v in model.state_dict().items() if v.is_floating_point() and "running" not in k}
+    bad = im.clone(); bad[0, 0, 1, 1] = float("nan")
+    with pytest.raises(RuntimeError, match="NaN loss"):
+        st.step(bad.to(dev), mk.to(dev))
+    for k, v in before.items():
+        assert torch.equal(model.state_dict()[k], v), k

@@ -4,7 +4,7 @@ from .unet import UNet, UNet_S, UNet_T, UNetDepth, DoubleConv, Down, Up, OutConv
 from .utils.dice_score import dice_coeff, multiclass_dice_coeff, dice_loss  # noqa: F401
 from .utils.boundary_loss import boundary_loss  # noqa: F401
 from .utils.connected_component_loss import connected_component_loss  # noqa: F401
-from .train import FusedRMSprop, seg_loss, train_step, TrainStepper  # noqa: F401
+from .train import FusedRMSprop, seg_loss, train_step, TrainStepper, GraphedTrainStepper  # noqa: F401
 from .evaluate import evaluate  # noqa: F401
 from .predict import predict_img, mask_to_image, preprocess_image  # noqa: F401
 from .checkpoint import save_checkpoint, load_checkpoint  # noqa: F401

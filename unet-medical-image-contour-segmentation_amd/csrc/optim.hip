@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, flo
                                                       float* __restrict__ buf, int64_t n, const float* __restrict__ total_norm,
                                                       float max_norm, float lr, float alpha, float eps, float wd, float mu) {
     float coef = 1.f;
+    // A NaN / infinite gradient norm means the loss was not finite (train.py:149-151 aborts before it gets here): leave the
+    // parameters and the optimizer state untouched, so that a step replayed from a captured graph -- where the host can
+    // only look at the loss afterwards -- cannot poison them either.
+    if (total_norm && !(fabsf(total_norm[0]) < __builtin_huge_valf())) return;
     if (max_norm > 0.f && total_norm) coef = fminf(max_norm / (total_norm[0] + 1e-6f), 1.f);
     const int64_t n4 = n >> 2;
     f32x4* p4 = reinterpret_cast<f32x4*>(p);

@@ -241,6 +241,73 @@ class TrainStepper:
                           reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan, cc_loss=self.cc_loss)
 
 
+class GraphedTrainStepper(TrainStepper):
+    """TrainStepper whose whole step (forward, loss, backward, clip + RMSprop) is captured once into a HIP graph and
+    replayed per batch: for launch-bound models (UNet_S / UNet_T: ~500 small kernels per step) the host no longer paces
+    the GPU.  Fixed batch shape; re-captured when the learning rate changes (it is a kernel argument); single process
+    only.  A NaN loss is detected after the replay (the fused optimizer kernel has skipped the update: non-finite norm)."""
+
+    def __init__(self, model: nn.Module, *args, warmup: int = 2, **kw):
+        super().__init__(model, *args, **kw)
+        if self.world != 1:
+            raise RuntimeError("GraphedTrainStepper is single-process; use TrainStepper with torch.distributed")
+        if self.cc_loss:
+            raise RuntimeError("connected_component_loss copies masks to the host every step: not capturable")
+        self._warmup = max(1, warmup)
+        self._graph = None
+        self._key = None
+
+    def _eager_step(self, images, masks):
+        self.model.train()
+        dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
+        if self._pack is None or self._pack.dtype != dt:
+            ws = [m.weight for m in self.model.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)]
+            self._pack = ops.ConvWeightPack(ws, dt) if ws and all(w.is_cuda for w in ws) else None
+        if self._pack is not None:
+            ops.WEIGHT_PACK = self._pack
+            self._pack.refresh()
+        return train_step(self.model, self.optimizer, images, masks, amp=self.amp, reduce_sums=self.reduce_sums,
+                          world=self.world, check_nan=False)
+
+    def _capture(self, images, masks):
+        opt = self.optimizer
+        # the warm-up steps the capture protocol needs must not count as training: snapshot, warm up, restore
+        snap_model = {k: v.clone() for k, v in self.model.state_dict().items()}
+        snap_opt = (opt.flat_p.clone(), opt.flat_sq.clone(), opt.flat_buf.clone())
+        self._im = images.detach().clone(memory_format=torch.preserve_format)
+        self._mk = masks.detach().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self._warmup):
+                self._eager_step(self._im, self._mk)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            opt.flat_p.copy_(snap_opt[0]); opt.flat_sq.copy_(snap_opt[1]); opt.flat_buf.copy_(snap_opt[2])
+            for k, v in self.model.state_dict().items():
+                if v.data_ptr() < opt.flat_p.data_ptr() or v.data_ptr() >= opt.flat_p.data_ptr() + opt.flat_p.numel() * 4:
+                    v.copy_(snap_model[k])                    # buffers (running statistics, num_batches_tracked)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            terms = self._eager_step(self._im, self._mk)
+            self._nan = torch.isnan(terms["loss"].detach()).reshape(1)
+        self._terms = terms
+        self._key = (tuple(images.shape), tuple(masks.shape), float(opt.param_groups[0]["lr"]))
+
+    def step(self, images, true_masks):
+        key = (tuple(images.shape), tuple(true_masks.shape), float(self.optimizer.param_groups[0]["lr"]))
+        if self._graph is None or key != self._key:
+            self._capture(images, true_masks)
+        self._im.copy_(images)
+        self._mk.copy_(true_masks)
+        self._graph.replay()
+        ops.WEIGHT_EPOCH += 1
+        if self.check_nan and bool(self._nan.item()):
+            raise RuntimeError("Fatal: NaN loss detected!")                                   # train.py:149-151
+        return self._terms
+
+
 # ----------------------------------------------------------------------------------- epoch loop
 def cosine_warm_restarts_lr(base_lr: float, epoch_arg: float, T_0: int = 4, T_mult: int = 2, eta_min: float = 1e-7):
     """CosineAnnealingWarmRestarts.step(epoch) closed form; train.py:187 passes the Dice score as
