@@ -80,11 +80,12 @@ int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
  * finalize: merge the conv's stat slabs (Chan's formula, double) -> mean, rstd = 1/sqrt(var_biased + eps),
  * scale = gamma*rstd, shift = beta - mean*scale; running stats (may be NULL) updated in place with
  * `momentum` and the UNBIASED variance (n = pixels per channel); *num_batches_tracked (int64 on the
- * device, may be NULL) += 1.  Slab rows whose pixel count is 0 are ignored. */
+ * device, may be NULL) += 1.  Slab rows whose pixel count is 0 are ignored.  m2_out (may be NULL): the merged
+ * M2 = sum (y - mean)^2 per channel -- with (mean, M2, n) per rank as rows, a second call merges ranks (SyncBN). */
 int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,
                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                    int64_t* num_batches_tracked, float momentum, float eps,
-                   float* scale, float* shift, float* mean, float* rstd, uh_stream stream);
+                   float* scale, float* shift, float* mean, float* rstd, float* m2_out, uh_stream stream);
 /* eval mode: scale/shift from the running statistics. */
 int uh_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift,
@@ -99,11 +100,14 @@ int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, int ldy,
                           const float* scale, const float* shift, const float* mean, const float* rstd,
                           float* partials, int64_t npix, int C, int dt, uh_stream stream);
 /* backward, pass 2: dgamma = sum2, dbeta = sum1 (written fp32), and
- * dy = scale*(dz*[z>0] - sum1/n - xhat*sum2/n). */
+ * dy = scale*(dz*[z>0] - sum1/n - xhat*sum2/n) with n = n_total (0: npix).  nblk == 0: dgamma / dbeta already hold
+ * the sums (e.g. all-reduced over the ranks of a data-parallel job: SyncBN, with n_total the global pixel count)
+ * and are only read.  uh_bn_bwd_finalize is the first half alone (partials -> dgamma, dbeta). */
+int uh_bn_bwd_finalize(const float* partials, int nblk, int C, float* dgamma, float* dbeta, uh_stream stream);
 int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int ldy,
                          const float* scale, const float* shift, const float* mean, const float* rstd,
                          const float* partials, int nblk, float* dgamma, float* dbeta,
-                         void* dy, int lddy, int64_t npix, int C, int dt, uh_stream stream);
+                         void* dy, int lddy, int64_t npix, int64_t n_total, int C, int dt, uh_stream stream);
 
 /* ---- nn.MaxPool2d(2)  (unet_parts.py:32) -------------------------------------------------- */
 int uh_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int dt,

@@ -26,7 +26,7 @@ for (B, H, W, C) in [(8, 512, 512, 64), (8, 256, 256, 128), (8, 128, 128, 256)]:
     nblk = LIB.query("uh_bn_bwd_nblk", n, C)
     part = torch.empty(nblk * 2 * C, device=dev)
     LIB.call("uh_bn_relu_bwd_reduce", a.data_ptr(), C, b.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), part.data_ptr(), n, C, 1, st)
-    tot.setdefault('bwd_apply', 0); tot['bwd_apply'] += timeit(lambda: LIB.call("uh_bn_relu_bwd_apply", a.data_ptr(), C, b.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), part.data_ptr(), nblk, dg.data_ptr(), db.data_ptr(), o.data_ptr(), C, n, C, 1, st), 3 * n * C * eb, "bn_relu_bwd_apply (+finalize)")
+    tot.setdefault('bwd_apply', 0); tot['bwd_apply'] += timeit(lambda: LIB.call("uh_bn_relu_bwd_apply", a.data_ptr(), C, b.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), part.data_ptr(), nblk, dg.data_ptr(), db.data_ptr(), o.data_ptr(), C, n, 0, C, 1, st), 3 * n * C * eb, "bn_relu_bwd_apply (+finalize)")
     x4 = a.view(B, H, W, C)
     p = torch.empty(B, H // 2, W // 2, C, device=dev, dtype=a.dtype)
     tot.setdefault('pool_fwd', 0); tot['pool_fwd'] += timeit(lambda: LIB.call("uh_maxpool2_fwd", x4.data_ptr(), C, p.data_ptr(), C, B, H, W, C, 1, st), 1.25 * n * C * eb, "maxpool2_fwd")

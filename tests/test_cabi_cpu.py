@@ -40,7 +40,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     with pytest.raises(RuntimeError, match="dtype"):
         LIB.call("uh_conv3x3_fwd", 16, 64, 64, None, 0, 0, 16, 16, 64, 64, None, 1, 16, 16, 7, None)
     with pytest.raises(RuntimeError, match="null pointer"):
-        LIB.call("uh_bn_finalize", None, 0, 0, 0, None, None, None, None, None, 0.1, 1e-5, None, None, None, None, None)
+        LIB.call("uh_bn_finalize", None, 0, 0, 0, None, None, None, None, None, 0.1, 1e-5, None, None, None, None, None, None)
 
 
 @pytest.mark.parametrize("fixture,ctor,args", [("g8_unet_t_bilinear", "UNet_T", (1, 1, True)),

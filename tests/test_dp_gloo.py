@@ -1,5 +1,5 @@
 """world_size-2 gloo tests (CPU) of the data-parallel plumbing in dp.py: bucketed asynchronous
-all-reduce (mean) of a flat gradient buffer in backward-ready order, and the loss-sum reducer that makes
+all-reduce (sum / mean) of a flat gradient buffer in backward-ready order, and the loss-sum reducer that makes
 Dice / BCE those of the GLOBAL batch."""
 import os
 import socket
@@ -32,17 +32,18 @@ def _worker(rank, world, port, q):
             off += (n + 3) // 4 * 4
         flat = torch.zeros(off)
         mine = torch.randn(off)
-        sync = dp.BucketedGradSync(flat, slices, bucket_bytes=4 * 1500)
-        assert len(sync.buckets) >= 3 and sync.buckets[0][0] == 0 and sync.buckets[-1][1] == off
-        for step in range(2):                      # two steps: state must reset
-            flat.copy_(mine * (step + 1))
-            for i in [0, 2, 1, 3, 5, 4, 6]:        # not exactly monotonic, like real autograd hooks
-                sync.mark_ready(i)
-            sync.wait()
-            gathered = [torch.zeros(off) for _ in range(world)]
-            dist.all_gather(gathered, mine * (step + 1))
-            want = sum(gathered) / world
-            assert torch.allclose(flat, want, atol=1e-6), f"rank {rank} step {step}"
+        for average in (False, True):              # SUM is what the train step uses (globally normalised loss)
+            sync = dp.BucketedGradSync(flat, slices, bucket_bytes=4 * 1500, average=average)
+            assert len(sync.buckets) >= 3 and sync.buckets[0][0] == 0 and sync.buckets[-1][1] == off
+            for step in range(2):                      # two steps: state must reset
+                flat.copy_(mine * (step + 1))
+                for i in [0, 2, 1, 3, 5, 4, 6]:        # not exactly monotonic, like real autograd hooks
+                    sync.mark_ready(i)
+                sync.wait()
+                gathered = [torch.zeros(off) for _ in range(world)]
+                dist.all_gather(gathered, mine * (step + 1))
+                want = sum(gathered) / (world if average else 1)
+                assert torch.allclose(flat, want, atol=1e-6), f"rank {rank} step {step} average {average}"
         # a parameter that never produced a gradient must not dead-lock the step
         flat.copy_(mine)
         sync.mark_ready(0)

@@ -69,3 +69,76 @@ def test_two_ranks_share_one_gpu_over_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _syncbn_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import unet_amd
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=False, sync_bn=True)
+        im, mk = unet_amd.ellipse_batch(4, 64, seed=21)
+        lo, hi = rank * 2, rank * 2 + 2
+        out = None
+        for _ in range(2):
+            out = stepper.step(im[lo:hi].to(dev), mk[lo:hi].to(dev))
+        torch.cuda.synchronize()
+        # numpy (pickled by value): torch tensors travel as shared-memory handles that die with this process
+        q.put((rank, "ok", stepper.optimizer.flat_p.cpu().numpy(), stepper.optimizer.flat_g.cpu().numpy(), float(out["bce"]),
+               float(out["dice"]), {k: v.cpu().numpy() for k, v in model.state_dict().items() if "running" in k}))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_sync_bn_data_parallel_equals_single_process():
+    """TrainStepper(sync_bn=True): two ranks with half the batch each == one process with the whole batch -- parameters,
+    (clipped) gradients, BatchNorm running statistics, BCE and Dice values.  This is the exact global-batch parity
+    option of SURVEY.md 8(e); the default per-rank BatchNorm is what stock DDP does."""
+    import unet_amd
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=False)
+    p0 = stepper.optimizer.flat_p.cpu().clone()
+    im, mk = unet_amd.ellipse_batch(4, 64, seed=21)
+    ref = None
+    for _ in range(2):
+        ref = stepper.step(im.to(dev), mk.to(dev))
+    torch.cuda.synchronize()
+    ref_p, ref_g = stepper.optimizer.flat_p.cpu(), stepper.optimizer.flat_g.cpu()
+    ref_run = {k: v.cpu() for k, v in model.state_dict().items() if "running" in k}
+    ref_bce, ref_dice = float(ref["bce"]), float(ref["dice"])
+    del stepper, model
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    for r in res:
+        _, _, fp, fg, bce, dice, run = r
+        fp, fg = torch.from_numpy(fp), torch.from_numpy(fg)
+        run = {k: torch.from_numpy(v) for k, v in run.items()}
+        assert abs(bce - ref_bce) < 1e-5 * max(1.0, abs(ref_bce)) and abs(dice - ref_dice) < 1e-5
+        gerr = float((fg - ref_g).norm() / ref_g.norm())
+        # RMSprop divides by sqrt(mean g^2): elements whose gradient is ~0 take sign-like steps of size ~lr that fp32
+        # round-off can flip, so the UPDATE is compared in L2 and every element to within one step size
+        uerr = float(((fp - p0) - (ref_p - p0)).norm() / (ref_p - p0).norm())
+        perr = float((fp - ref_p).abs().max())
+        assert gerr < 1e-3, f"gradient rel L2 {gerr:.3e}"
+        assert uerr < 2e-2 and perr < 1.5e-4, f"update rel L2 {uerr:.3e}, max abs diff {perr:.3e}"
+        for k, v in ref_run.items():
+            assert torch.allclose(run[k], v, rtol=1e-4, atol=1e-6), k
+    assert (res[0][2] == res[1][2]).all()

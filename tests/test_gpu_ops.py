@@ -274,10 +274,16 @@ def test_bn_relu_forward_backward(dtype, B, H, W, C):
     dy = torch.empty_like(yg)
     LIB.call("uh_bn_relu_bwd_apply", dzg.data_ptr(), C, yg.data_ptr(), C, scale.data_ptr(), shift.data_ptr(),
              meang.data_ptr(), rstdg.data_ptr(), part.data_ptr(), nblk, dgam.data_ptr(), dbet.data_ptr(), dy.data_ptr(), C,
-             n, C, dtc, st)
+             n, 0, C, dtc, st)
     tol = 2e-5 if dtype == torch.float32 else 1e-2
     assert _rel(dgam, dgr) < 2e-5 and _rel(dbet, dbr) < 2e-5
     assert _rel(dy.permute(0, 3, 1, 2), dyr) < tol
+    # the split form used by SyncBN: finalize alone, then apply with ready sums (nblk = 0) and an explicit n
+    dg2, db2, dy2 = torch.empty_like(dgam), torch.empty_like(dbet), torch.empty_like(dy)
+    LIB.call("uh_bn_bwd_finalize", part.data_ptr(), nblk, C, dg2.data_ptr(), db2.data_ptr(), st)
+    LIB.call("uh_bn_relu_bwd_apply", dzg.data_ptr(), C, yg.data_ptr(), C, scale.data_ptr(), shift.data_ptr(),
+             meang.data_ptr(), rstdg.data_ptr(), None, 0, dg2.data_ptr(), db2.data_ptr(), dy2.data_ptr(), C, n, n, C, dtc, st)
+    assert torch.equal(dg2, dgam) and torch.equal(db2, dbet) and torch.equal(dy2, dy)
 
 
 def test_rmsprop_clip_flat():

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ rvar, float momentum, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                           long long* __restrict__ nbt) {
+                                                           long long* __restrict__ nbt, float* __restrict__ m2_o) {
     // block = 16 channels x 64 row lanes (C/16 blocks, each thread walks R/64 rows)
     __shared__ double red[3][16][16];
     __shared__ int last_row;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     shift[c] = bt - (float)mean * sc;
     mean_o[c] = (float)mean;
     rstd_o[c] = rstd;
+    if (m2_o) m2_o[c] = (float)m.m2;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) {
         double unb = n > 1.0 ? m.m2 / (n - 1.0) : var;
@@ -99,13 +100,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                               float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
-                              uh_stream stream) {
+                              float* m2_out, uh_stream stream) {
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
     UH_REQUIRE(nslab > 0 && C > 0 && n > 0, "uh_bn_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
-                       (long long*)num_batches_tracked);
+                       (long long*)num_batches_tracked, m2_out);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
     return UH_OK;
 }
@@ -366,17 +367,27 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
     }
 }
 
+extern "C" int uh_bn_bwd_finalize(const float* partials, int nblk, int C, float* dgamma, float* dbeta, uh_stream stream) {
+    UH_REQUIRE(partials && dgamma && dbeta && nblk > 0 && C > 0, "uh_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, nblk, C, dgamma,
+                       dbeta);
+    UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    return UH_OK;
+}
+
 extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int ldy, const float* scale,
                                     const float* shift, const float* mean, const float* rstd, const float* partials,
-                                    int nblk, float* dgamma, float* dbeta, void* dy, int lddy, int64_t npix, int C,
-                                    int dt, uh_stream stream) {
-    UH_REQUIRE(dz && y && scale && shift && mean && rstd && partials && dgamma && dbeta && dy,
-               "uh_bn_relu_bwd_apply: null pointer");
-    UH_REQUIRE(npix > 0 && C > 0 && nblk > 0 && lddz >= C && ldy >= C && lddy >= C, "uh_bn_relu_bwd_apply: bad sizes");
+                                    int nblk, float* dgamma, float* dbeta, void* dy, int lddy, int64_t npix,
+                                    int64_t n_total, int C, int dt, uh_stream stream) {
+    UH_REQUIRE(dz && y && scale && shift && mean && rstd && dgamma && dbeta && dy, "uh_bn_relu_bwd_apply: null pointer");
+    UH_REQUIRE(npix > 0 && C > 0 && nblk >= 0 && (nblk == 0 || partials) && lddz >= C && ldy >= C && lddy >= C,
+               "uh_bn_relu_bwd_apply: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
-    UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
-    float inv_n = (float)(1.0 / (double)npix);
+    if (nblk > 0) {          // nblk == 0: dgamma / dbeta already hold the (possibly cross-rank) sums
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
+        UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    }
+    float inv_n = (float)(1.0 / (double)(n_total > 0 ? n_total : npix));
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
         if (uh_vec_ok<T>(dz, lddz, C) && uh_vec_ok<T>(y, ldy, C) && uh_vec_ok<T>(dy, lddy, C)) {

@@ -3,8 +3,10 @@
 The reference is single-process; data parallelism is introduced here at the
 three places SURVEY.md 8(e) names:
   * gradients: the flat fp32 gradient buffer of FusedRMSprop is cut into contiguous buckets in
-    backward-ready order (decoder first); a bucket is all-reduced (async, on RCCL's own stream) as
-    soon as its last gradient has been produced, so the transfers overlap the encoder backward;
+    backward-ready order (decoder first); a bucket is all-reduced (SUM, async, on RCCL's own stream) as
+    soon as its last gradient has been produced, so the transfers overlap the encoder backward.  SUM, not
+    mean: the loss of every rank is already normalised by the GLOBAL batch (BCE mean over n*world pixels,
+    Dice ratio of all-reduced sums), so the rank gradients are the per-shard terms of ONE global gradient;
   * Dice / BCE: the 4 (binary) or 1+3C (multi-class) partial sums are all-reduced before the
     ratio is formed, so loss value and gradient are those of the GLOBAL batch;
   * BatchNorm: per-rank batch statistics (what stock DDP does) -- stated in DESIGN.md.
@@ -35,10 +37,11 @@ def make_sum_reducer(group=None):
 
 
 class BucketedGradSync:
-    """All-reduce (mean) a flat gradient buffer in contiguous buckets as their slices become ready."""
+    """All-reduce (sum; `average=True` for a mean) a flat gradient buffer in contiguous buckets as their slices become
+    ready."""
 
     def __init__(self, flat_grad: torch.Tensor, slices: Sequence[Tuple[int, int]], bucket_bytes: int = 8 << 20,
-                 group=None):
+                 group=None, average: bool = False):
         self.flat = flat_grad
         self.group = group
         self.world = world_size(group)
@@ -58,7 +61,8 @@ class BucketedGradSync:
         self.members = [0] * len(self.buckets)
         for b in self.bucket_of:
             self.members[b] += 1
-        self._use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.average = average
+        self._use_avg = average and dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.reset()
 
     def reset(self):
@@ -93,6 +97,6 @@ class BucketedGradSync:
                 self._launch(b)
         for h, view in self.handles:
             h.wait()
-            if not self._use_avg and self.world > 1:
+            if self.average and not self._use_avg and self.world > 1:
                 view.div_(self.world)
         self.reset()

@@ -330,6 +330,34 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
 
 
 # ----------------------------------------------------------------------------- conv + BN + ReLU
+# (process group, world size) when BatchNorm statistics are to be those of the GLOBAL batch of a data-parallel job
+# (TrainStepper(sync_bn=True)); None = per-rank statistics (what stock DDP does).
+SYNC_BN = None
+
+
+def _sync_bn_forward(coef, m2, n_local, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps):
+    """Merge the per-rank (count, mean, M2) rows into the global-batch statistics: one all_gather of 2C+1 floats per
+    layer, then the same uh_bn_finalize over `world` rows (Chan merge in double), which also updates the running
+    statistics with the global unbiased variance.  Returns the global pixel count."""
+    import torch.distributed as dist
+    group, world = SYNC_BN
+    dev = coef.device
+    mean = coef[2 * Cout:3 * Cout]
+    row = torch.cat([mean, m2, torch.full((1,), float(n_local), dtype=torch.float32, device=dev)])
+    gathered = torch.empty(world * (2 * Cout + 1), dtype=torch.float32, device=dev)
+    dist.all_gather(list(gathered.view(world, 2 * Cout + 1).unbind(0)), row, group=group)
+    g2 = gathered.view(world, 2 * Cout + 1)
+    stats = torch.empty(world * (2 * Cout + 2), dtype=torch.float32, device=dev)
+    stats[:world * 2 * Cout].view(world, 2 * Cout).copy_(g2[:, :2 * Cout])
+    stats[world * 2 * Cout:world * 2 * Cout + world].copy_(g2[:, 2 * Cout])
+    n_total = int(n_local) * world                      # equal shards (bench / DDP convention)
+    scale, shift, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[3 * Cout:]
+    LIB.call("uh_bn_finalize", stats.data_ptr(), world, Cout, n_total, g32.data_ptr(), b32.data_ptr(),
+             _p(running_mean), _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(),
+             mean.data_ptr(), rstd.data_ptr(), None, _stream())
+    return n_total
+
+
 class ConvBnReluFn(Function):
     """(nn.Conv2d(3x3, pad 1, no bias) -> nn.BatchNorm2d -> nn.ReLU) of unet_parts.py:15-17 / 18-20 as
     one autograd node.  Inputs: x0 (+ optional x1 = second half of the channel concat of
@@ -362,9 +390,19 @@ class ConvBnReluFn(Function):
             y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True)
             nbt = num_batches_tracked
             fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
-            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(),
-                     _p(running_mean), _p(running_var), nbt.data_ptr() if fused_nbt else None, float(momentum),
-                     float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream())
+            nbt_ptr = nbt.data_ptr() if fused_nbt else None
+            n_total = n
+            if SYNC_BN is None:
+                LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(),
+                         _p(running_mean), _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(),
+                         shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, _stream())
+            else:
+                # local (mean, M2) first -- running statistics untouched -- then the cross-rank merge
+                m2 = torch.empty(Cout, dtype=torch.float32, device=dev)
+                LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(), None, None,
+                         None, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                         rstd.data_ptr(), m2.data_ptr(), _stream())
+                n_total = _sync_bn_forward(coef, m2, n, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps)
             if nbt is not None and not fused_nbt:
                 nbt.add_(1)
         else:
@@ -385,6 +423,8 @@ class ConvBnReluFn(Function):
         ctx.bn_params = (gamma, beta)
         ctx.training = training
         ctx.dims = (B, H, W, C0, C1, Cout)
+        ctx.n_total = n_total
+        ctx.sync_bn = SYNC_BN if n_total != n else None
         return z
 
     @staticmethod
@@ -406,9 +446,20 @@ class ConvBnReluFn(Function):
         gamma_p, beta_p = ctx.bn_params
         (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
         dy = torch.empty_like(y)
-        LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
-                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
-                 dbeta.data_ptr(), dy.data_ptr(), Cout, n, Cout, dt, _stream())
+        if ctx.sync_bn is None:
+            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
+                     dbeta.data_ptr(), dy.data_ptr(), Cout, n, 0, Cout, dt, _stream())
+        else:
+            # SyncBN: the parameter gradients stay LOCAL sums (the gradient all-reduce averages them like every other
+            # gradient); the dx formula needs the GLOBAL sums and the global pixel count
+            import torch.distributed as dist
+            LIB.call("uh_bn_bwd_finalize", partials.data_ptr(), nblk, Cout, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+            glob = torch.cat([dgamma.reshape(-1), dbeta.reshape(-1)])
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.sync_bn[0])
+            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, 0, glob[:Cout].data_ptr(),
+                     glob[Cout:].data_ptr(), dy.data_ptr(), Cout, n, ctx.n_total, Cout, dt, _stream())
         # backward-data first: it is the only consumer on the critical path (the next layer's BatchNorm backward waits
         # for it).  Backward-weights then goes to the side stream BEHIND it, so that it runs beside the HBM-bound
         # kernels of the layers that follow (BatchNorm backward, pool / upsample backward) instead of beside this

@@ -213,7 +213,7 @@ class TrainStepper:
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
                  gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
-                 wgrad_stream: bool = True, cc_loss: bool = False):
+                 wgrad_stream: bool = True, cc_loss: bool = False, sync_bn: bool = False):
         self.model = model
         if wgrad_stream and ops.WGRAD_STREAM is None:
             ops.WGRAD_STREAM = torch.cuda.Stream()
@@ -223,12 +223,17 @@ class TrainStepper:
         self.group = process_group
         self.world = dpmod.world_size(process_group)
         self.reduce_sums = dpmod.make_sum_reducer(process_group)
+        # sync_bn: BatchNorm statistics (forward) and their backward sums over the GLOBAL batch -> the data-parallel step
+        # reproduces the single-process step on the concatenated batch (SURVEY.md 8e option 2); default = per-rank
+        # statistics like stock DDP.  One all_gather (2C+1 floats) + one all_reduce (2C floats) per BatchNorm layer.
+        self.sync_bn = (process_group, self.world) if (sync_bn and self.world > 1) else None
         self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
                                       gradient_clipping=gradient_clipping, process_group=process_group)
         self._pack = None
 
     def step(self, images, true_masks):
         self.model.train()
+        ops.SYNC_BN = self.sync_bn
         # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
@@ -259,6 +264,7 @@ class GraphedTrainStepper(TrainStepper):
 
     def _eager_step(self, images, masks):
         self.model.train()
+        ops.SYNC_BN = None
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
             ws = [m.weight for m in self.model.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)]
