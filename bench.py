@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity path) instead of bf16")
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
+    ap.add_argument("--bf16x3", action="store_true", help="with --fp32: 3x3 conv products on the bf16 matrix pipe (hi/lo splits)")
     ap.add_argument("--cc-loss", action="store_true", help="add connected_component_loss to the loss value (config 5)")
     ap.add_argument("--config4", action="store_true",
                     help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
@@ -144,7 +145,8 @@ def main():
         model = unet_amd.UNet(1, 1, bilinear=bilinear)
     model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
-    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream, cc_loss=args.cc_loss)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream, cc_loss=args.cc_loss,
+                                   fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact")
     g = torch.Generator().manual_seed(1 + rank)
     B, S = args.batch, args.size
     images = torch.rand(B, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -216,7 +218,8 @@ def main():
             "metric": f"images/sec (train step) UNet {n_in}x{S}x{S}->{n_cls}",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if amp else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if amp else ("f32 (3x3 fwd/dgrad as bf16x3 split products)" if args.bf16x3 else "f32"),
+            "data": "synthetic",
             "config": {"workload": (f"UNet({n_in},{n_cls},bilinear={bilinear}{', depth 5' if args.config4 else ''}) train step "
                                     f"({'BCE' if n_cls == 1 else 'CE'}+Dice+boundary, clip 1.0, RMSprop), "
                                     f"{B} x {n_in}x{S}x{S} per GPU, global batch {B * world}"),

@@ -346,3 +346,58 @@ def test_batched_weight_pack_matches_per_layer(dtype):
     assert torch.equal(hit[0], wf) and torch.equal(hit[1], wd)
     ops.WEIGHT_EPOCH += 1                             # raw-pointer optimizer update -> every entry is stale
     assert pack.lookup(ws[0], dtype) is None
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 32, 32, 64, 0, 128), (2, 17, 23, 64, 64, 64), (1, 40, 24, 128, 128, 128),
+                                               (2, 8, 8, 512, 0, 512), (1, 448, 448, 64, 0, 64), (8, 64, 64, 16, 0, 64)])
+def test_conv3x3_bf16x3_split_products(B, H, W, C0, C1, Cout):
+    """fp32 tensors, products on the bf16 matrix pipe (UH_F32X3): w*x ~= wh*xh + wh*xl + wl*xh.  Forward, the fused
+    inference epilogue and backward-data against fp64; the error budget is ~2^-17 per product (1e-5), asserted at 1e-4."""
+    from unet_amd import ops
+    from unet_amd._lib import LIB, UH_F32X3
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + C0 + Cout)
+    Cin = C0 + C1
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    xd, wd_ = x.double().requires_grad_(True), w.double()
+    yref = F.conv2d(xd, wd_, padding=1)
+    (dxref,) = torch.autograd.grad(yref, xd, dy.double())
+    xg = _nhwc(x, torch.float32, dev)
+    x0, x1 = xg[..., :C0], (xg[..., C0:] if C1 else None)
+    need_dx = Cin % 64 == 0
+    wf, wdg = ops.pack_w3x3(w.to(dev), torch.float32, need_dx, UH_F32X3)
+    y, stats, nslab = ops.conv3x3_fwd(x0, x1, wf, Cout, True, UH_F32X3)
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    e = rel(y.permute(0, 3, 1, 2), yref.detach())
+    assert e < 1e-4, f"fwd {e:.3e}"
+    yx, _, _ = ops.conv3x3_fwd(x0, x1, ops.pack_w3x3(w.to(dev), torch.float32, False)[0], Cout, False)      # exact fp32 MFMA
+    assert rel(y.permute(0, 3, 1, 2), yx.permute(0, 3, 1, 2).double().cpu()) < 1e-4
+    st = stats[:nslab * 2 * Cout].view(nslab, 2, Cout).double().cpu()
+    cnt = stats[nslab * 2 * Cout:nslab * 2 * Cout + nslab].double().cpu()
+    live = cnt > 0
+    mean = (st[live, 0] * cnt[live, None]).sum(0) / cnt.sum()
+    assert float((mean - y.double().cpu().reshape(-1, Cout).mean(0)).abs().max()) < 1e-5 * float(y.abs().max()) + 1e-7
+    if need_dx:
+        dx, _, _ = ops.conv3x3_fwd(_nhwc(dy, torch.float32, dev), None, wdg, Cin, False, UH_F32X3)
+        e = rel(dx.permute(0, 3, 1, 2), dxref)
+        assert e < 1e-4, f"dgrad {e:.3e}"
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.3).to(dev)
+    z = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
+    LIB.call("uh_conv3x3_fwd_affine_relu", x0.data_ptr(), C0, ops.pixel_ld(x0), None if x1 is None else x1.data_ptr(), C1,
+             0 if x1 is None else ops.pixel_ld(x1), wf.data_ptr(), z.data_ptr(), Cout, Cout, sc.data_ptr(), sh.data_ptr(),
+             B, H, W, UH_F32X3, torch.cuda.current_stream().cuda_stream)
+    zref = F.relu(yref.detach() * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None])
+    assert rel(z.permute(0, 3, 1, 2), zref) < 1e-4
+
+
+def test_bf16x3_rejects_unaligned_shapes():
+    from unet_amd import ops
+    from unet_amd._lib import UH_F32X3
+    dev = _dev()
+    x = torch.randn(1, 8, 8, 24, device=dev)
+    w = torch.randn(16, 24, 3, 3, device=dev)
+    wf, _ = ops.pack_w3x3(w, torch.float32, False, UH_F32X3)
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        ops.conv3x3_fwd(x, None, wf, 16, False, UH_F32X3)

@@ -470,3 +470,25 @@ def test_graph_captured_step_matches_eager(ctor, bilinear, amp):
         st.step(bad.to(dev), mk.to(dev))
     for k, v in before.items():
         assert torch.equal(model.state_dict()[k], v), k
+
+
+def test_full_unet_step_fp32_bf16x3_vs_oracle():
+    """fp32_mode='bf16x3' (3x3 forward / backward-data products on the bf16 matrix pipe, fp32 everywhere else) against the
+    CPU oracle: logits and loss well inside the 1e-3 parity bar; gradients like the exact fp32 path (ill-conditioned, L2)."""
+    import unet_amd
+    from oracle import step_ref as S
+    dev = _dev()
+    torch.manual_seed(3)
+    model = unet_amd.UNet(1, 1, bilinear=False)
+    g = torch.Generator().manual_seed(4)
+    images = torch.rand(2, 1, 64, 64, generator=g)
+    masks = torch.randint(0, 3, (2, 64, 64), generator=g)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    _, _, ref = S.train_step(state, None, images, masks, n_classes=1, bilinear=False)
+    model = model.to(dev)
+    st = unet_amd.TrainStepper(model, amp=False, fp32_mode="bf16x3")
+    t = st.step(images.to(dev), masks.to(dev))
+    torch.cuda.synchronize()
+    check(t["logits"], ref["logits"], 2e-4, "bf16x3 logits")
+    check(t["loss"], ref["loss"], 1e-4, "bf16x3 loss")
+    check(t["grad_norm"], ref["grad_norm"], 3e-2, "bf16x3 grad norm")

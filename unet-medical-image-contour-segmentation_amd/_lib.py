@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "unet_hip.h")
 # UH_LIB_PATH points the binding at another build of the same C ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("UH_LIB_PATH") or os.path.join(PKG_DIR, "libunet_hip.so")
 
-UH_F32, UH_BF16 = 0, 1
+UH_F32, UH_BF16, UH_F32X3 = 0, 1, 2
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,

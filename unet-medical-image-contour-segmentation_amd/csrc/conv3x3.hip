@@ -50,12 +50,39 @@ __global__ void unpack_dw3x3_kernel(const float* __restrict__ dwk, float* __rest
     dw[o * sO + i * sI + r * sH + s * sW] = dwk[idx];
 }
 
+// bf16x3 pack: hi = bf16(w), lo = bf16(w - hi); forward copy [hi | lo] x [o][tap][i], backward-data copy [hi | lo] x [i][tap'][o]
+__global__ void pack_w3x3_split_kernel(const float* __restrict__ w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout,
+                                       int Cin, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)Cout * 9 * Cin;
+    if (idx >= total) return;
+    int i = (int)(idx % Cin);
+    int t = (int)((idx / Cin) % 9);
+    int o = (int)(idx / (9 * (int64_t)Cin));
+    int r = t / 3, s = t - 3 * r;
+    const float v = w[o * sO + i * sI + r * sH + s * sW];
+    const bf16_t h = (bf16_t)v, l = (bf16_t)(v - (float)h);
+    wf[idx] = h;
+    wf[total + idx] = l;
+    if (wd) {
+        const int64_t k = (((int64_t)i * 3 + (2 - r)) * 3 + (2 - s)) * Cout + o;
+        wd[k] = h;
+        wd[total + k] = l;
+    }
+}
+
 extern "C" int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
                             void* w_fwd, void* w_dgrad, int dt, uh_stream stream) {
     UH_REQUIRE(w && w_fwd && Cout > 0 && Cin > 0, "uh_pack_w3x3: bad arguments");
     int64_t total = (int64_t)Cout * 9 * Cin;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (dt == UH_F32X3) {
+        hipLaunchKernelGGL(pack_w3x3_split_kernel, grid, block, 0, st, w, sO, sI, sH, sW, Cout, Cin, (bf16_t*)w_fwd,
+                           (bf16_t*)w_dgrad);
+        UH_CHECK_LAUNCH("pack_w3x3_split_kernel");
+        return UH_OK;
+    }
     if (dt == UH_BF16)
         hipLaunchKernelGGL(pack_w3x3_kernel<bf16_t>, grid, block, 0, st, w, sO, sI, sH, sW, Cout, Cin,
                            (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
@@ -387,7 +414,11 @@ constexpr unsigned OOB_OFFSET = 0xF0000000u;
 // distinct 16-byte slots of the 256-byte bank row -> conflict-free fragment reads for all nine taps.
 __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }   // hx = halo COLUMN (0..17)
 
-template <typename T, int NBW>
+// SPLIT (T = float only, "bf16x3"): fp32 tensors, but the products run on the bf16 matrix pipe, 16x faster than the fp32
+// one on this chip: x = xh + xl and w = wh + wl with bf16 halves (filters pre-split by uh_pack_w3x3, pixels split in
+// registers as their fragment arrives), and  w*x ~= wh*xh + wh*xl + wl*xh  (the dropped wl*xl term and the second
+// roundings are ~2^-17 relative: 1e-5, against a 1e-3 parity bar), accumulated in fp32 by v_mfma_f32_16x16x16_bf16.
+template <typename T, int NBW, bool SPLIT = false>
 __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
@@ -474,6 +505,33 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 
     const T* wl = w + (int64_t)(co_w + lx) * 9 * Cin + kg * VEC;
     const int64_t wnb_stride = (int64_t)16 * 9 * Cin;
+    // SPLIT: `w` holds two bf16 arrays [Cout][9][Cin] (hi then lo); a fragment = 4 hi + 4 lo values in one u32x4
+    const bf16_t* wsh = reinterpret_cast<const bf16_t*>(w) + (int64_t)(co_w + lx) * 9 * Cin + kg * 4;
+    const int64_t wlo_off = (int64_t)Cout * 9 * Cin;
+    auto wfrag = [&](int64_t off) -> u32x4 {             // off = n * wnb_stride + tap * Cin + chunk offset (elements)
+        if constexpr (SPLIT) {
+            const u32x2 h = *reinterpret_cast<const u32x2*>(wsh + off);
+            const u32x2 l = *reinterpret_cast<const u32x2*>(wsh + wlo_off + off);
+            return u32x4{h[0], h[1], l[0], l[1]};
+        } else {
+            return *reinterpret_cast<const u32x4*>(wl + off);
+        }
+    };
+    // fp32 pixel fragment (4 channels) -> {hi pair, hi pair, lo pair, lo pair} as bf16
+    auto split4 = [&](u32x4& f) {
+        const f32x4 x = __builtin_bit_cast(f32x4, f);
+        bf16_t h[4];
+        unsigned lo[2], hi[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = (bf16_t)x[q];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bf16_t l0 = (bf16_t)(x[2 * q] - (float)h[2 * q]), l1 = (bf16_t)(x[2 * q + 1] - (float)h[2 * q + 1]);
+            hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h[2 * q]) | ((unsigned)__builtin_bit_cast(unsigned short, h[2 * q + 1]) << 16);
+            lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        f = u32x4{hi[0], hi[1], lo[0], lo[1]};
+    };
 
     // Persistent over tiles: the DMA of the NEXT tile's first chunk is issued under the last chunk of the current
     // tile, so a workgroup never waits for a cold HBM round trip after its first tile (matters for the
@@ -487,7 +545,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int n = 0; n < NBW; ++n) wc[r][n] = *reinterpret_cast<const u32x4*>(wl + n * wnb_stride + (r * 3) * Cin);
+        for (int n = 0; n < NBW; ++n) wc[r][n] = wfrag(n * wnb_stride + (int64_t)(r * 3) * Cin);
     __syncthreads();     // drains the DMA (vmcnt(0)) before anyone reads buffer 0
     int bufi = 0;
 
@@ -507,17 +565,16 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 dma_chunk(pix_cur, 0, bufi ^ 1);
             }
             const unsigned char* buf = lds + bufi * HALO2_BYTES;
-            const T* wcp = wl + c * CK;
-            const T* wcp_next = wl + ((c + 1 < nchunk) ? (c + 1) : 0) * CK;      // wraps to chunk 0 of the next tile
+            const int64_t wcp = (int64_t)c * CK;
+            const int64_t wcp_next = (int64_t)((c + 1 < nchunk) ? (c + 1) : 0) * CK;   // wraps to chunk 0 of the next tile
 #pragma unroll 1
             for (int s = 0; s < 3; ++s) {
                 // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
-                const T* wsrc = (s < 2) ? (wcp + (s + 1) * Cin) : wcp_next;
+                const int64_t wsrc = (s < 2) ? (wcp + (int64_t)(s + 1) * Cin) : wcp_next;
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n)
-                        wn[r][n] = *reinterpret_cast<const u32x4*>(wsrc + n * wnb_stride + (r * 3) * Cin);
+                    for (int n = 0; n < NBW; ++n) wn[r][n] = wfrag(wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
                 __builtin_amdgcn_sched_barrier(0);
                 // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
                 u32x4 xf[18];
@@ -530,6 +587,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 for (int k = 2; k < 18; ++k) {
                     if (k + PF < 18) xf[k + PF] = rd(k + PF);     // PF rows ahead of the row being multiplied
                     __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
+                    if constexpr (SPLIT) {                  // row k's fragment is first used now: split it once
+                        if (k == 2) { split4(xf[0]); split4(xf[1]); }
+                        split4(xf[k]);
+                    }
                     const int i = k - 2;
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
@@ -538,6 +599,14 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                             if constexpr (ES == 2) {
                                 acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                     __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                            } else if constexpr (SPLIT) {
+                                const s16x4 wh = __builtin_bit_cast(s16x4, u32x2{wc[r][n][0], wc[r][n][1]});
+                                const s16x4 wlo = __builtin_bit_cast(s16x4, u32x2{wc[r][n][2], wc[r][n][3]});
+                                const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{xf[i + r][0], xf[i + r][1]});
+                                const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xf[i + r][2], xf[i + r][3]});
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[i][n], 0, 0, 0);
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xlo, acc[i][n], 0, 0, 0);
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[i][n], 0, 0, 0);
                             } else {
                                 f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
                                 f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
@@ -1079,7 +1148,7 @@ extern "C" int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int
 template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
-                                const float* ep_shift, bool* ep_done) {
+                                const float* ep_shift, bool* ep_done, bool split = false) {
     // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
     // runs the separate scale/shift/ReLU pass
     *ep_done = false;
@@ -1104,19 +1173,32 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                 return gx;
             };
             if (ep_scale && !(uh_aligned16(ep_scale) && uh_aligned16(ep_shift))) ep_scale = ep_shift = nullptr;   // 16-B loads
+            constexpr bool CAN_SPLIT = (ES == 4);
+            if (split && !CAN_SPLIT) { uh_set_error("conv3x3_fwd: bf16x3 needs fp32 tensors"); return UH_EINVAL; }
             if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                if (split) {
+                    if constexpr (CAN_SPLIT)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                } else
+                    hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
-                hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                   C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                if (split) {
+                    if constexpr (CAN_SPLIT)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                } else
+                    hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
             *ep_done = ep_scale != nullptr;
             return UH_OK;
         }
+        if (split) { uh_set_error("conv3x3_fwd: bf16x3 is implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (Cout % 128 == 0) {
             hipLaunchKernelGGL((conv3x3_fwd_mfma<T, 4>), dim3(ntile, Cout / 128), dim3(256), 0, st, x0, C0, ld0, x1, C1,
                                ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY);
@@ -1127,6 +1209,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         UH_CHECK_LAUNCH("conv3x3_fwd_mfma");
         return UH_OK;
     }
+    if (split) { uh_set_error("conv3x3_fwd: bf16x3 needs an MFMA-aligned shape (Cin %% 16 == 0, Cout %% 64 == 0, 16-byte strides)"); return UH_EINVAL; }
     if (Cin <= 4 && C1 == 0) {
         constexpr int V = 16 / ES;
         if constexpr (ES == 2) {
@@ -1174,14 +1257,14 @@ extern "C" int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, i
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd: bad shape");
     UH_REQUIRE(ld0 >= C0 && ldy >= Cout && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_fwd: bad strides");
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd: pixel count overflows int32");
-    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_conv3x3_fwd: bad dtype %d", dt);
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_fwd: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
     bool done;
     if (dt == UH_BF16)
         return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w,
                                             (bf16_t*)y, ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done);
     return conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)y,
-                                       ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done);
+                                       ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done, dt == UH_F32X3);
 }
 
 // Inference forward: z = max(conv(x, w) * scale + shift, 0) with the eval-mode BatchNorm coefficients of
@@ -1194,7 +1277,7 @@ extern "C" int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd_affine_relu: bad shape");
     UH_REQUIRE(ld0 >= C0 && ldz >= Cout && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_fwd_affine_relu: bad strides");
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd_affine_relu: pixel count overflows int32");
-    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_conv3x3_fwd_affine_relu: bad dtype %d", dt);
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_fwd_affine_relu: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     int rc;
@@ -1203,9 +1286,9 @@ extern "C" int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const
                                           (bf16_t*)z, ldz, Cout, nullptr, B, H, W, st, scale, shift, &done);
     else
         rc = conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)z,
-                                         ldz, Cout, nullptr, B, H, W, st, scale, shift, &done);
+                                         ldz, Cout, nullptr, B, H, W, st, scale, shift, &done, dt == UH_F32X3);
     if (rc != UH_OK || done) return rc;
-    return uh_bn_relu_apply(z, ldz, scale, shift, z, ldz, (int64_t)B * H * W, Cout, dt, stream);
+    return uh_bn_relu_apply(z, ldz, scale, shift, z, ldz, (int64_t)B * H * W, Cout, dt == UH_BF16 ? UH_BF16 : UH_F32, stream);
 }
 
 // =====================================================================================

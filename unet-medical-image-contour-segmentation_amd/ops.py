@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 from torch.autograd import Function
 
-from ._lib import LIB, UH_BF16, UH_F32
+from ._lib import LIB, UH_BF16, UH_F32, UH_F32X3
 
 BN_EPS_DEFAULT = 1e-5
 
@@ -149,14 +149,30 @@ def _is_krsc_dense(w: torch.Tensor) -> bool:
 
 
 # ----------------------------------------------------------------------------- raw op wrappers
-def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool):
+# How fp32 activations are convolved: "exact" = fp32 MFMA (157 TFLOP/s peak, the parity path); "bf16x3" = products on the
+# bf16 matrix pipe with hi/lo splits of both operands (forward / backward-data 3x3 convs of MFMA-aligned layers; ~1e-5
+# relative, backward-weights stays exact).  Set by TrainStepper(fp32_mode=...) / bench.py --bf16x3.
+FP32_MODE = "exact"
+
+
+def conv_dt(x: torch.Tensor, C0: int, C1: int, Cout: int, need_dx: bool) -> int:
+    """dtype code for the 3x3 conv calls of one layer (pack + forward + backward-data use the SAME code)."""
+    if x.dtype == torch.float32 and FP32_MODE == "bf16x3":
+        Cin = C0 + C1
+        if Cin > 4 and C0 % 16 == 0 and C1 % 16 == 0 and Cout % 64 == 0 and (not need_dx or Cin % 64 == 0):
+            return UH_F32X3
+    return _dt(x)
+
+
+def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool, dt_code: Optional[int] = None):
     O, I = weight.shape[0], weight.shape[1]
     w32 = weight if weight.dtype == torch.float32 else weight.float()
     wf = torch.empty(O * 9 * I, dtype=dtype, device=weight.device)
     wd = torch.empty(O * 9 * I, dtype=dtype, device=weight.device) if need_dgrad else None
     sO, sI, sH, sW = w32.stride()
-    LIB.call("uh_pack_w3x3", w32.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), _p(wd),
-             UH_BF16 if dtype == torch.bfloat16 else UH_F32, _stream())
+    if dt_code is None:
+        dt_code = UH_BF16 if dtype == torch.bfloat16 else UH_F32
+    LIB.call("uh_pack_w3x3", w32.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), _p(wd), dt_code, _stream())
     return wf, wd
 
 
@@ -224,6 +240,8 @@ class ConvWeightPack:
 
     def lookup(self, weight: torch.Tensor, dtype: torch.dtype):
         """-> (w_fwd, w_dgrad) views if the pack holds the CURRENT value of `weight` in `dtype`, else None."""
+        if FP32_MODE != "exact" and dtype == torch.float32:
+            return None                          # bf16x3 layers pack their own [hi | lo] copies
         i = self.index.get(weight.data_ptr())
         if i is None or dtype != self.dtype or self.epoch != WEIGHT_EPOCH or self.versions[i] != weight._version \
                 or self.strides[i] != tuple(weight.stride()):
@@ -238,10 +256,10 @@ WEIGHT_PACK: Optional[ConvWeightPack] = None
 
 
 def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, Cout: int,
-                want_stats: bool):
+                want_stats: bool, dt_code: Optional[int] = None):
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
-    dt = _dt(x0)
+    dt = _dt(x0) if dt_code is None else dt_code
     y = torch.empty((B, H, W, Cout), dtype=x0.dtype, device=x0.device)
     stats, nslab = None, 0
     if want_stats:
@@ -375,11 +393,15 @@ class ConvBnReluFn(Function):
         if Cin != C0 + C1:
             raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
         need_dx = any(ctx.needs_input_grad[:2])
+        cdt = conv_dt(x0, C0, C1, Cout, need_dx and training)
         if training:
-            hit = WEIGHT_PACK.lookup(weight, x0.dtype) if WEIGHT_PACK is not None else None
-            wf, wd = hit if hit is not None else pack_w3x3(weight, x0.dtype, need_dx)
+            hit = WEIGHT_PACK.lookup(weight, x0.dtype) if (WEIGHT_PACK is not None and cdt != UH_F32X3) else None
+            wf, wd = hit if hit is not None else pack_w3x3(weight, x0.dtype, need_dx, cdt)
+        elif cdt == UH_F32X3:
+            wf, wd = pack_w3x3(weight, x0.dtype, False, cdt)[0], None
         else:
             wf, wd = packed_w3x3_cached(weight, x0.dtype), None
+        ctx.cdt = cdt
         dev = x0.device
         coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
         scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
@@ -387,7 +409,7 @@ class ConvBnReluFn(Function):
         g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
         b32 = beta if beta.dtype == torch.float32 else beta.float()
         if training:
-            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True)
+            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt)
             nbt = num_batches_tracked
             fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
             nbt_ptr = nbt.data_ptr() if fused_nbt else None
@@ -413,7 +435,7 @@ class ConvBnReluFn(Function):
             z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
             LIB.call("uh_conv3x3_fwd_affine_relu", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
                      pixel_ld(x1) if x1 is not None else 0, wf.data_ptr(), z.data_ptr(), Cout, Cout, scale.data_ptr(),
-                     shift.data_ptr(), B, H, W, _dt(x0), _stream())
+                     shift.data_ptr(), B, H, W, cdt, _stream())
             ctx.training = False
             return z
         z = torch.empty_like(y)
@@ -466,7 +488,7 @@ class ConvBnReluFn(Function):
         # layer's own MFMA-bound backward-data.
         dx0 = dx1 = None
         if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False)
+            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt)
             dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
             dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)

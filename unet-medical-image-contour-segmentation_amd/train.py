@@ -213,12 +213,15 @@ class TrainStepper:
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
                  gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
-                 wgrad_stream: bool = True, cc_loss: bool = False, sync_bn: bool = False):
+                 wgrad_stream: bool = True, cc_loss: bool = False, sync_bn: bool = False, fp32_mode: str = "exact"):
         self.model = model
         if wgrad_stream and ops.WGRAD_STREAM is None:
             ops.WGRAD_STREAM = torch.cuda.Stream()
         self.amp = amp
         self.check_nan = check_nan
+        if fp32_mode not in ("exact", "bf16x3"):
+            raise ValueError("fp32_mode must be 'exact' or 'bf16x3'")
+        self.fp32_mode = fp32_mode          # how fp32 activations are convolved (ops.FP32_MODE); irrelevant under amp
         self.cc_loss = cc_loss
         self.group = process_group
         self.world = dpmod.world_size(process_group)
@@ -234,6 +237,7 @@ class TrainStepper:
     def step(self, images, true_masks):
         self.model.train()
         ops.SYNC_BN = self.sync_bn
+        ops.FP32_MODE = self.fp32_mode
         # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
@@ -265,6 +269,7 @@ class GraphedTrainStepper(TrainStepper):
     def _eager_step(self, images, masks):
         self.model.train()
         ops.SYNC_BN = None
+        ops.FP32_MODE = self.fp32_mode
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
             ws = [m.weight for m in self.model.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)]
