@@ -33,8 +33,9 @@ typedef void* uh_stream;            /* hipStream_t */
 enum { UH_F32 = 0, UH_BF16 = 1,
        /* fp32 tensors, 3x3 conv products on the bf16 matrix pipe ("bf16x3": w*x ~= wh*xh + wh*xl + wl*xh with bf16
         * halves, fp32 accumulate, ~1e-5 relative).  Accepted by uh_pack_w3x3 (writes [hi | lo] bf16 arrays of
-        * Cout*9*Cin elements each into the same number of bytes as the fp32 pack), uh_conv3x3_fwd and
-        * uh_conv3x3_fwd_affine_relu (MFMA-aligned shapes only: Cin % 16 == 0, Cout % 64 == 0). */
+        * Cout*9*Cin elements each into the same number of bytes as the fp32 pack), uh_conv3x3_fwd,
+        * uh_conv3x3_fwd_affine_relu (MFMA-aligned shapes only: Cin % 16 == 0, Cout % 64 == 0) and uh_conv3x3_wgrad
+        * (channel counts multiples of 64). */
        UH_F32X3 = 2 };
 enum { UH_OK = 0, UH_EINVAL = -1, UH_ELAUNCH = -2, UH_EWORKSPACE = -3 };
 

@@ -401,3 +401,26 @@ def test_bf16x3_rejects_unaligned_shapes():
     wf, _ = ops.pack_w3x3(w, torch.float32, False, UH_F32X3)
     with pytest.raises(RuntimeError, match="bf16x3"):
         ops.conv3x3_fwd(x, None, wf, 16, False, UH_F32X3)
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 32, 32, 64, 0, 128), (2, 17, 23, 64, 64, 64), (1, 40, 24, 128, 128, 128), (2, 8, 8, 512, 0, 512)])
+def test_conv3x3_wgrad_bf16x3(B, H, W, C0, C1, Cout):
+    """backward-weights with bf16x3 split products (fp32 dy and x, v_mfma_f32_32x32x8_bf16 x3) against fp64."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + C0 + Cout + 1)
+    Cin = C0 + C1
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    wd_ = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (dwref,) = torch.autograd.grad(F.conv2d(x.double(), wd_, padding=1), wd_, dy.double())
+    xg = _nhwc(x, torch.float32, dev)
+    x0, x1 = xg[..., :C0], (xg[..., C0:] if C1 else None)
+    dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
+    ops.conv3x3_wgrad(_nhwc(dy, torch.float32, dev), x0, x1, dwk, split=True)
+    got = dwk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu()
+    e = float((got - dwref).abs().max() / dwref.abs().max())
+    assert e < 1e-4, f"wgrad bf16x3 {e:.3e}"
+    dwx = torch.empty_like(dwk)
+    ops.conv3x3_wgrad(_nhwc(dy, torch.float32, dev), x0, x1, dwx)                  # exact fp32 MFMA
+    assert float((dwk - dwx).abs().max() / dwx.abs().max()) < 1e-4

@@ -1308,7 +1308,9 @@ template <> struct WgradCfg<float> { static constexpr int TH = 8; };
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <typename T>
+// SPLIT (T = float, "bf16x3"): both operands are split into bf16 halves as their fragments leave LDS and the three
+// products dh*xh + dh*xl + dl*xh run on v_mfma_f32_32x32x8_bf16 (see conv3x3_fwd_mfma_v2).
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit) {
@@ -1423,6 +1425,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
                         // tap (r, s): x halo row hy pairs with dy row hy - r (valid 0 <= hy - r < TH)
                         if (hy - r >= 0 && hy - r < TH)
                             acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag[r], xf, acc[r * 3 + s], 0, 0, 0);
+                    }
+                }
+            }
+        } else if constexpr (SPLIT) {
+            // 32x32x8 bf16 operand: lane l holds row/col (l & 31), k = 4*(l >> 5) + j: 4 consecutive pixels of one channel.
+            // A tile row of 16 pixels = two K groups of 8.  fragment = {hi01, hi23, lo01, lo23} (bf16 pairs).
+            const int l32 = lane & 31, kh = lane >> 5;
+            auto load_split = [&](const unsigned char* base) -> u32x4 {      // base -> pixel 0 of this lane's 4 pixels
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float*>(base + j * PB);
+                bf16_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { h[j] = (bf16_t)v[j]; l[j] = (bf16_t)(v[j] - (float)h[j]); }
+                auto pk = [](bf16_t a, bf16_t b) -> unsigned {
+                    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+                };
+                return u32x4{pk(h[0], h[1]), pk(h[2], h[3]), pk(l[0], l[1]), pk(l[2], l[3])};
+            };
+            u32x4 dfrag[3][2];                                 // dy rows hy, hy-1, hy-2  x  K group
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dfrag[k][0] = dfrag[k][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll 1
+            for (int hy = 0; hy < TH + 2; ++hy) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    dfrag[2][g] = dfrag[1][g];
+                    dfrag[1][g] = dfrag[0][g];
+                    dfrag[0][g] = (hy < TH) ? load_split(ds + (hy * TILE + g * 8 + kh * 4) * PB + (wr * 32 + l32) * 4)
+                                            : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const u32x4 xfr = load_split(xs + (hy * HALO_W + s + g * 8 + kh * 4) * PB + (wc * 32 + l32) * 4);
+                        const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{xfr[0], xfr[1]});
+                        const s16x4 xl = __builtin_bit_cast(s16x4, u32x2{xfr[2], xfr[3]});
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            if (hy - r >= 0 && hy - r < TH) {
+                                const s16x4 dh = __builtin_bit_cast(s16x4, u32x2{dfrag[r][g][0], dfrag[r][g][1]});
+                                const s16x4 dl = __builtin_bit_cast(s16x4, u32x2{dfrag[r][g][2], dfrag[r][g][3]});
+                                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(dl, xh, acc[r * 3 + s], 0, 0, 0);
+                                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(dh, xl, acc[r * 3 + s], 0, 0, 0);
+                                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(dh, xh, acc[r * 3 + s], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -1940,13 +1990,18 @@ extern "C" size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
 
 template <typename T>
 static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, int ld0, const T* x1, int C1, int ld1,
-                                  float* dw, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, hipStream_t st) {
+                                  float* dw, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, hipStream_t st,
+                                  bool split = false) {
     constexpr int ES = sizeof(T);
     const int Cin = C0 + C1;
     const bool aligned = uh_aligned16(dy) && uh_aligned16(x0) && (C1 == 0 || uh_aligned16(x1)) && (lddy * ES) % 16 == 0 &&
                          (ld0 * ES) % 16 == 0 && (C1 == 0 || (ld1 * ES) % 16 == 0) && (C0 % 64 == 0);
     WgradPlan p = wgrad_plan<T>(B, H, W, Cin, Cout, aligned);
     if (p.kind == 1 && C1 != 0) p.kind = 2;
+    if (split && p.kind != 0) {
+        uh_set_error("uh_conv3x3_wgrad: bf16x3 needs an MFMA-aligned shape (channel counts multiples of 64, 16-byte strides)");
+        return UH_EINVAL;
+    }
     if (p.kind == 2) {
         hipLaunchKernelGGL(conv3x3_wgrad_generic<T>, dim3(Cout * 9), dim3(256), 0, st, dy, lddy, x0, C0, ld0, x1, C1, ld1,
                            dw, Cout, B, H, W);
@@ -1974,8 +2029,13 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             }
         }
         if (!dma) {
-            hipLaunchKernelGGL(conv3x3_wgrad_mfma<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy, lddy,
-                               x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+            if (split) {
+                if constexpr (ES == 4)
+                    hipLaunchKernelGGL((conv3x3_wgrad_mfma<T, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+            } else
+                hipLaunchKernelGGL(conv3x3_wgrad_mfma<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy, lddy,
+                                   x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
             UH_CHECK_LAUNCH("conv3x3_wgrad_mfma");
         }
     } else {
@@ -2018,11 +2078,11 @@ extern "C" int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_wgrad: bad shape");
     UH_REQUIRE(lddy >= Cout && ld0 >= C0 && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_wgrad: bad strides");
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_wgrad: pixel count overflows int32");
-    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_conv3x3_wgrad: bad dtype %d", dt);
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_wgrad: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
     if (dt == UH_BF16)
         return conv3x3_wgrad_dispatch<bf16_t>((const bf16_t*)dy, lddy, (const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1,
                                               ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st);
     return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
-                                         dw_krsc, Cout, ws, ws_bytes, B, H, W, st);
+                                         dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3);
 }

@@ -272,12 +272,15 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
     return y, stats, nslab
 
 
-def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], out_krsc: torch.Tensor):
+def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], out_krsc: torch.Tensor,
+                  split: bool = False):
     B, H, W, Cout = dy.shape
     C0 = x0.shape[3]
     C1 = 0 if x1 is None else x1.shape[3]
     dt = _dt(dy)
     nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, C0 + C1, Cout, dt)
+    if split and dt == UH_F32 and C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0:
+        dt = UH_F32X3                          # bf16x3 products (ops.FP32_MODE); same workspace as the fp32 plan
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     name = "conv3x3_wgrad_" + ("mfma" if (C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0) else
                                 ("stem" if C0 + C1 <= 4 else "generic"))
@@ -501,15 +504,15 @@ class ConvBnReluFn(Function):
                 ev.record()                         # dy (and this layer's backward-data) are enqueued before this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    conv3x3_wgrad(dy, x0, x1, dweight)
+                    conv3x3_wgrad(dy, x0, x1, dweight, ctx.cdt == UH_F32X3)
                 for t_ in (dy, x0, x1):
                     if t_ is not None:
                         t_.record_stream(side)      # the caching allocator must not recycle them under the side stream
             elif _is_krsc_dense(weight):
-                conv3x3_wgrad(dy, x0, x1, dweight)
+                conv3x3_wgrad(dy, x0, x1, dweight, ctx.cdt == UH_F32X3)
             else:
                 dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
-                conv3x3_wgrad(dy, x0, x1, dwk)
+                conv3x3_wgrad(dy, x0, x1, dwk, ctx.cdt == UH_F32X3)
                 sO, sI, sH, sW = dweight.stride()
                 LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
             if cb_w is not None:
