@@ -424,3 +424,33 @@ def test_conv3x3_wgrad_bf16x3(B, H, W, C0, C1, Cout):
     dwx = torch.empty_like(dwk)
     ops.conv3x3_wgrad(_nhwc(dy, torch.float32, dev), x0, x1, dwx)                  # exact fp32 MFMA
     assert float((dwk - dwx).abs().max() / dwx.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,h,w,Cin,Ho,Wo", [(2, 16, 16, 128, 32, 32), (2, 8, 8, 64, 17, 19), (4, 32, 32, 256, 64, 64)])
+def test_conv_transpose_bf16x3(B, h, w, Cin, Ho, Wo):
+    """ConvTranspose2d k2 s2 in fp32 with bf16x3 split products (ops.FP32_MODE) against fp64."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(Cin + 5)
+    Cout = Cin // 2
+    x = torch.randn(B, Cin, h, w, generator=g)
+    wt = torch.randn(Cin, Cout, 2, 2, generator=g) / (Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    cot = torch.randn(B, Cout, Ho, Wo, generator=g)
+    xd, wd, bd = x.double().requires_grad_(True), wt.double().requires_grad_(True), bias.double().requires_grad_(True)
+    up = F.conv_transpose2d(xd, wd, bd, stride=2)
+    dY, dX = Ho - up.shape[2], Wo - up.shape[3]
+    ref = F.pad(up, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])
+    dxr, dwr, dbr = torch.autograd.grad(ref, [xd, wd, bd], cot.double())
+    old = ops.FP32_MODE
+    ops.FP32_MODE = "bf16x3"
+    try:
+        xg = _nhwc(x, torch.float32, dev).requires_grad_(True)
+        wg, bg = wt.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+        y = ops.ConvTranspose2x2PadFn.apply(xg, wg, bg, Ho, Wo)
+        y.backward(_nhwc(cot, torch.float32, dev))
+    finally:
+        ops.FP32_MODE = old
+    assert _rel(y.permute(0, 3, 1, 2), ref.detach()) < 1e-4
+    assert _rel(xg.grad.permute(0, 3, 1, 2), dxr) < 1e-4
+    assert _rel(wg.grad, dwr) < 1e-4 and _rel(bg.grad, dbr) < 2e-5

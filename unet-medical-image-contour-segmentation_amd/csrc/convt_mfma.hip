@@ -46,7 +46,9 @@ __device__ __forceinline__ int ctm_out_pixel(const CtmGeom& g, int m, int q) {
     return (b * g.Ho + oy) * g.Wo + ox;
 }
 
-template <typename T, int MODE>
+// SPLIT (T = float, "bf16x3", dtype code UH_F32X3): both fp32 fragments are split into bf16 hi/lo halves as they leave
+// LDS and the three products ah*bh + ah*bl + al*bh run on v_mfma_f32_16x16x16_bf16 (fp32 accumulate, ~1e-5 relative).
+template <typename T, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void ctm_gemm_kernel(CtmArgs<T> a) {
     constexpr int ES = sizeof(T);
     constexpr int CK = 64 / ES;                // K elements per 64-byte chunk
@@ -149,11 +151,33 @@ __global__ __launch_bounds__(256, 2) void ctm_gemm_kernel(CtmArgs<T> a) {
         // order makes the compiler drain the DMA first) and lands under the 16 MFMAs
         if (kc + 1 < kc_end) dma_chunk(kc + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPLIT) {                 // 4 floats -> {hi01, hi23, lo01, lo23}
+            auto split4 = [](u32x4& f) {
+                const f32x4 x = __builtin_bit_cast(f32x4, f);
+                unsigned hi[2], lo[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bf16_t h0 = (bf16_t)x[2 * q], h1 = (bf16_t)x[2 * q + 1];
+                    const bf16_t l0 = (bf16_t)(x[2 * q] - (float)h0), l1 = (bf16_t)(x[2 * q + 1] - (float)h1);
+                    hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                f = u32x4{hi[0], hi[1], lo[0], lo[1]};
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { split4(fa[i]); split4(fb[i]); }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (ES == 2) {
+                if constexpr (SPLIT) {
+                    const s16x4 ah = __builtin_bit_cast(s16x4, u32x2{fa[i][0], fa[i][1]}), al = __builtin_bit_cast(s16x4, u32x2{fa[i][2], fa[i][3]});
+                    const s16x4 bh = __builtin_bit_cast(s16x4, u32x2{fb[j][0], fb[j][1]}), bl = __builtin_bit_cast(s16x4, u32x2{fb[j][2], fb[j][3]});
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[i][j], 0, 0, 0);
+                } else if constexpr (ES == 2) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
                                                                         __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
                 } else {
@@ -340,6 +364,7 @@ constexpr long long CT_MAX_BYTES = (1ll << 31) - 4096;
 // ------------------------------------------------------------------------------------ C ABI (MFMA path)
 extern "C" int uh_convt2x2_pack(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dt, uh_stream stream) {
     UH_REQUIRE(w && w_fwd && w_dgrad && Cin > 0 && Cout > 0, "uh_convt2x2_pack: bad args");
+    if (dt == UH_F32X3) dt = UH_F32;                 // bf16x3 splits both operands in registers: plain fp32 copies
     UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_convt2x2_pack: bad dtype %d", dt);
     long long total = (long long)Cin * Cout * 4, g = (total + 255) / 256;
     if (g > 8192) g = 8192;
@@ -353,6 +378,7 @@ extern "C" int uh_convt2x2_pack(const float* w, int Cin, int Cout, void* w_fwd, 
 
 // 1 when the MFMA kernels take this problem (else the callers use the SIMT path of convt_1x1.hip)
 extern "C" int uh_convt2x2_mfma_ok(int B, int h, int w_, int Cin, int Cout, int Ho, int Wo, int dt) {
+    if (dt == UH_F32X3) dt = UH_F32;                 // same tensors, same shape rules
     const int ES = dt == UH_BF16 ? 2 : 4, CK = 64 / ES;
     const long long M = (long long)B * h * w_;
     if (Cin % CK || Cout % CK || M >= (1ll << 30) || M % CK) return 0;
@@ -368,6 +394,8 @@ extern "C" int uh_convt2x2_fwd_mfma(const void* x, int ldx, const void* w_fwd, c
     UH_REQUIRE(uh_convt2x2_mfma_ok(B, h, w_, Cin, Cout, Ho, Wo, dt), "uh_convt2x2_fwd_mfma: shape not supported");
     UH_REQUIRE(uh_aligned16(x) && uh_aligned16(y) && uh_aligned16(w_fwd) && uh_aligned16(bias), "uh_convt2x2_fwd_mfma: alignment");
     hipStream_t st = (hipStream_t)stream;
+    const bool split = dt == UH_F32X3;
+    if (split) dt = UH_F32;
     const long long M = (long long)B * h * w_;
     const bool border = !(pad_top == 0 && pad_left == 0 && Ho == 2 * h && Wo == 2 * w_);
     UH_DISPATCH_DT(dt, T, {
@@ -384,8 +412,13 @@ extern "C" int uh_convt2x2_fwd_mfma(const void* x, int ldx, const void* w_fwd, c
         a.K = Cin; a.kchunks_per_split = 0;
         a.g = ctm_geom(B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
         a.bias = bias; a.out = (T*)y; a.ldo = ldy; a.slabs = nullptr;
-        hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_FWD>), dim3((unsigned)((M + 127) / 128), (4 * Cout + 127) / 128, 1), dim3(256),
-                           0, st, a);
+        if (split) {
+            if constexpr (sizeof(T) == 4)
+                hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_FWD, true>), dim3((unsigned)((M + 127) / 128), (4 * Cout + 127) / 128, 1),
+                                   dim3(256), 0, st, a);
+        } else
+            hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_FWD>), dim3((unsigned)((M + 127) / 128), (4 * Cout + 127) / 128, 1), dim3(256),
+                               0, st, a);
     });
     UH_CHECK_LAUNCH("ctm_gemm_kernel<fwd>");
     return UH_OK;
@@ -398,6 +431,8 @@ extern "C" int uh_convt2x2_dgrad_mfma(const void* dy, int lddy, const void* w_dg
     UH_REQUIRE(uh_convt2x2_mfma_ok(B, h, w_, Cin, Cout, Ho, Wo, dt), "uh_convt2x2_dgrad_mfma: shape not supported");
     UH_REQUIRE(uh_aligned16(dy) && uh_aligned16(dx) && uh_aligned16(w_dgrad), "uh_convt2x2_dgrad_mfma: alignment");
     hipStream_t st = (hipStream_t)stream;
+    const bool split = dt == UH_F32X3;
+    if (split) dt = UH_F32;
     const long long M = (long long)B * h * w_;
     UH_DISPATCH_DT(dt, T, {
         UH_REQUIRE((lddy * (int)sizeof(T)) % 16 == 0 && (lddx * (int)sizeof(T)) % 8 == 0, "uh_convt2x2_dgrad_mfma: strides");
@@ -410,15 +445,20 @@ extern "C" int uh_convt2x2_dgrad_mfma(const void* dy, int lddy, const void* w_dg
         a.K = 4 * Cout; a.kchunks_per_split = 0;
         a.g = ctm_geom(B, h, w_, Cin, Cout, Ho, Wo, pad_top, pad_left);
         a.bias = nullptr; a.out = (T*)dx; a.ldo = lddx; a.slabs = nullptr;
-        hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_DGRAD>), dim3((unsigned)((M + 127) / 128), (Cin + 127) / 128, 1), dim3(256), 0,
-                           st, a);
+        if (split) {
+            if constexpr (sizeof(T) == 4)
+                hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_DGRAD, true>), dim3((unsigned)((M + 127) / 128), (Cin + 127) / 128, 1),
+                                   dim3(256), 0, st, a);
+        } else
+            hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_DGRAD>), dim3((unsigned)((M + 127) / 128), (Cin + 127) / 128, 1), dim3(256), 0,
+                               st, a);
     });
     UH_CHECK_LAUNCH("ctm_gemm_kernel<dgrad>");
     return UH_OK;
 }
 
 static int ctm_wgrad_plan(int B, int h, int w_, int Cin, int Cout, int dt, int* chunks_per_split) {
-    const int ES = dt == UH_BF16 ? 2 : 4, CK = 64 / ES;
+    const int ES = dt == UH_BF16 ? 2 : 4, CK = 64 / ES;       // UH_F32X3 plans like UH_F32
     const long long M = (long long)B * h * w_;
     const int nchunk = (int)(M / CK);
     const int tiles = ((4 * Cout + 127) / 128) * ((Cin + 127) / 128);
@@ -456,6 +496,8 @@ extern "C" int uh_convt2x2_wgrad_mfma(const void* dy, int lddy, const void* x, i
     }
     UH_REQUIRE(uh_aligned16(ws), "uh_convt2x2_wgrad_mfma: workspace alignment");
     hipStream_t st = (hipStream_t)stream;
+    const bool split = dt == UH_F32X3;
+    if (split) dt = UH_F32;
     const long long M = (long long)B * h * w_;
     int cps;
     const int nsplit = ctm_wgrad_plan(B, h, w_, Cin, Cout, dt, &cps);
@@ -478,8 +520,13 @@ extern "C" int uh_convt2x2_wgrad_mfma(const void* dy, int lddy, const void* x, i
         a.b_bytes = (unsigned)((size_t)Cin * M * sizeof(T));
         a.K = (int)M; a.kchunks_per_split = cps;
         a.g = g; a.bias = nullptr; a.out = nullptr; a.ldo = 0; a.slabs = slabs;
-        hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_WGRAD>), dim3((Cin + 127) / 128, (4 * Cout + 127) / 128, nsplit), dim3(256), 0, st,
-                           a);
+        if (split) {
+            if constexpr (sizeof(T) == 4)
+                hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_WGRAD, true>), dim3((Cin + 127) / 128, (4 * Cout + 127) / 128, nsplit),
+                                   dim3(256), 0, st, a);
+        } else
+            hipLaunchKernelGGL((ctm_gemm_kernel<T, CT_WGRAD>), dim3((Cin + 127) / 128, (4 * Cout + 127) / 128, nsplit), dim3(256), 0, st,
+                               a);
         const long long nw = (long long)Cin * Cout * 4;
         hipLaunchKernelGGL(ctm_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)slabs, nsplit,
                            Cin, Cout, dw);

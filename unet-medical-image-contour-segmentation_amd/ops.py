@@ -631,6 +631,8 @@ class ConvTranspose2x2PadFn(Function):
         y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         dt = _dt(x)
         mfma = bool(LIB.query("uh_convt2x2_mfma_ok", B, h, w, Cin, Cout, Ho, Wo, dt))
+        if mfma and dt == UH_F32 and FP32_MODE == "bf16x3":
+            dt = UH_F32X3                    # split products on the bf16 matrix pipe (both operands split in registers)
         wd = None
         if mfma:
             wf = torch.empty(Cin * Cout * 4, dtype=x.dtype, device=x.device)
@@ -644,6 +646,7 @@ class ConvTranspose2x2PadFn(Function):
                      B, h, w, Cin, Cout, Ho, Wo, pt, pl, dt, _stream())
         ctx.save_for_backward(x, wc, wd)
         ctx.geom = (B, h, w, Cin, Cout, Ho, Wo, pt, pl)
+        ctx.dt = dt
         return y
 
     @staticmethod
@@ -651,7 +654,7 @@ class ConvTranspose2x2PadFn(Function):
         x, wc, wd = ctx.saved_tensors
         B, h, w, Cin, Cout, Ho, Wo, pt, pl = ctx.geom
         dy = dense_nhwc(dy if dy.dtype == x.dtype else dy.to(x.dtype))
-        dt = _dt(x)
+        dt = ctx.dt
         mfma = wd is not None
         flops = 2.0 * B * h * w * Cin * 4 * Cout
         dx = None
