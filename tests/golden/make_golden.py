@@ -14,7 +14,8 @@ model/loss modules through the statement sequence of train.py:113-159 using stoc
 
 Fixture list: G1 DoubleConv, G2 Down, G3 Up bilinear (+odd-size pad),
 G4 Up convT, G5 OutConv, G6 Dice, G7 boundary_loss, G8 UNet_T 3-step trajectories,
-G9 full UNet scalars, G10 eval-mode logits/masks, G11 depth-5 net from reference parts.
+G9 full UNet scalars, G10 eval-mode logits/masks, G11 depth-5 net from reference parts,
+G12 utils/data_loading.BasicDataset items on synthetic PNG files.
 """
 import os
 import sys
