@@ -210,7 +210,10 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
         # the layer the north-star names: the 256-channel DoubleConv (down2: 128->256->256 at 128x128, batch 8)
-        kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
+        try:
+            kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
+        except Exception as e:                      # an optional extra must never cost the headline line
+            kernels["double_conv_256"] = {"error": repr(e)}
 
     if rank == 0:
         ips = world * B * args.steps / elapsed
@@ -233,23 +236,32 @@ def main():
         }
         if world == 1 and not args.no_inference:
             # forward-only inference (model.eval(): running statistics folded into the conv epilogue)
-            model.eval()
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                for _ in range(3):
-                    model(images)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    logits = model(images)
-                e1.record()
-                torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
-            out["inference"] = {"images_per_sec": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "batch": B,
-                                "what": "eval-mode forward, fused conv+BN(running stats)+ReLU kernels, logits only"}
+            try:
+                model.eval()
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    for _ in range(3):
+                        model(images)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        model(images)
+                    e1.record()
+                    torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                out["inference"] = {"images_per_sec": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "batch": B,
+                                    "what": "eval-mode forward, fused conv+BN(running stats)+ReLU kernels, logits only"}
+            except Exception as e:                  # optional extras never cost the headline line
+                out["inference"] = {"error": repr(e)}
             model.train()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S)
-            out["cpu_baseline"]["dice_vs_ref"] = dice_vs_ref()
+            try:
+                out["cpu_baseline"] = cpu_baseline(S)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+            try:
+                out["cpu_baseline"]["dice_vs_ref"] = dice_vs_ref()
+            except Exception as e:
+                out["cpu_baseline"]["dice_vs_ref"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
