@@ -1,96 +1,107 @@
-"""Directory dataset of the reference (/root/reference/utils/data_loading.py:14-136): grey-level
-images + masks coded {0: ghost, 128: background, 255: contour}, optional x4 rotation augmentation, BICUBIC / NEAREST
-rescale, label remap to {0, 1, 2}.  Host-side (PIL + numpy), same constructor / item contract:
+"""Directory dataset with the reference's item contract (behaviour of
+/root/reference/utils/data_loading.py:14-136, pinned bit for bit by fixture G12):
 
-    BasicDataset(images_dir, mask_dir, scale=1.0, mask_suffix='_mask', augment=True)
-    len(ds) == n_files * (4 if augment else 1);  ds[i] -> {'image': float32 [C,H,W], 'mask': int64 [H,W]}
-    ds.mask_values   sorted unique raw mask values over the directory (stored in checkpoints, train.py:213)
+    ds = BasicDataset(images_dir, mask_dir, scale=1.0, mask_suffix='_mask', augment=True)
+    len(ds)        = files x 4 quarter-turn rotations when augment (item i: file i // 4, rotation i % 4), else files
+    ds[i]          = {'image': float32 [C, H, W] in [0, 1], 'mask': int64 [H, W] in {0, 1, 2}}
+    ds.mask_values = sorted raw grey levels found in the mask files (travels inside checkpoints, train.py:213)
+
+Masks are grey images coded 0 = ghost, 128 = background, 255 = contour -> classes 0 / 1 / 2 through a 256-entry lookup
+table; images are rescaled with BICUBIC, masks with NEAREST, and an image is divided by 255 only when it holds a value
+above 1.  Host-side (PIL + numpy): feeding the GPU path is the DataLoader's job.
 """
 from __future__ import annotations
 
-from os import listdir
-from os.path import isfile, join, splitext
+import os
 from pathlib import Path
+from typing import Dict, List
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-ROTATIONS = (0, 90, 180, 270)          # data_loading.py:108-111: index // 4 = file, index % 4 = rotation
+QUARTER_TURNS = 4
+_CLASS_OF_GREY = np.zeros(256, dtype=np.int8)
+_CLASS_OF_GREY[128] = 1
+_CLASS_OF_GREY[255] = 2
 
 
 def load_image(filename):
+    """PIL image from an image file, a .npy array or a saved tensor (.pt / .pth)."""
     from PIL import Image
-    ext = splitext(str(filename))[1]
-    if ext == ".npy":
+    suffix = Path(str(filename)).suffix
+    if suffix == ".npy":
         return Image.fromarray(np.load(filename))
-    if ext in (".pt", ".pth"):
+    if suffix in {".pt", ".pth"}:
         return Image.fromarray(torch.load(filename).numpy())
     return Image.open(filename)
 
 
-def _unique_values(mask_file) -> np.ndarray:
-    m = np.asarray(load_image(mask_file))
-    if m.ndim == 2:
-        return np.unique(m)
-    if m.ndim == 3:
-        return np.unique(m.reshape(-1, m.shape[-1]), axis=0)
-    raise ValueError(f"Loaded masks should have 2 or 3 dimensions, found {m.ndim}")
+def _grey_levels(path) -> np.ndarray:
+    arr = np.asarray(load_image(path))
+    if arr.ndim not in (2, 3):
+        raise ValueError(f"Loaded masks should have 2 or 3 dimensions, found {arr.ndim}")
+    return np.unique(arr) if arr.ndim == 2 else np.unique(arr.reshape(-1, arr.shape[-1]), axis=0)
+
+
+def _rescaled(pil_img, scale: float, resample):
+    width, height = pil_img.size
+    size = (int(scale * width), int(scale * height))
+    assert min(size) > 0, "Scale is too small, resized images would have no pixel"
+    return pil_img.resize(size, resample=resample)
+
+
+def _quarter_turn(pil_img, turns: int):
+    """`turns` x 90 degrees counter-clockwise with the canvas following the image (what Image.rotate(angle, expand=True)
+    does for right angles: a lossless transpose)."""
+    from PIL import Image
+    op = {1: Image.ROTATE_90, 2: Image.ROTATE_180, 3: Image.ROTATE_270}.get(turns % QUARTER_TURNS)
+    return pil_img if op is None else pil_img.transpose(op)
 
 
 class BasicDataset(Dataset):
     def __init__(self, images_dir: str, mask_dir: str, scale: float = 1.0, mask_suffix: str = "_mask", augment=True):
-        self.images_dir = Path(images_dir)
-        self.mask_dir = Path(mask_dir)
         assert 0 < scale <= 1, "Scale must be between 0 and 1"
-        self.scale = scale
-        self.mask_suffix = mask_suffix
-        self.augment = augment
-        self.ids = [splitext(f)[0] for f in listdir(images_dir) if isfile(join(images_dir, f)) and not f.startswith(".")]
+        self.images_dir, self.mask_dir = Path(images_dir), Path(mask_dir)
+        self.scale, self.mask_suffix, self.augment = scale, mask_suffix, augment
+        self.ids: List[str] = [os.path.splitext(name)[0] for name in os.listdir(images_dir)
+                               if not name.startswith(".") and (self.images_dir / name).is_file()]
         if not self.ids:
             raise RuntimeError(f"No input file found in {images_dir}, make sure you put your images there")
-        uniq = [_unique_values(list(self.mask_dir.glob(i + self.mask_suffix + ".*"))[0]) for i in self.ids]
-        self.mask_values = list(sorted(np.unique(np.concatenate(uniq), axis=0).tolist()))
+        levels = [_grey_levels(self._only(self.mask_dir, stem + mask_suffix, "mask")) for stem in self.ids]
+        self.mask_values = sorted(np.unique(np.concatenate(levels), axis=0).tolist())
 
-    def __len__(self):
-        return len(self.ids) * (len(ROTATIONS) if self.augment else 1)
+    @staticmethod
+    def _only(folder: Path, stem: str, what: str) -> Path:
+        hits = list(folder.glob(stem + ".*"))
+        assert len(hits) == 1, f"Either no {what} or multiple {what}s found for the ID {stem}: {hits}"
+        return hits[0]
+
+    def __len__(self) -> int:
+        return len(self.ids) * (QUARTER_TURNS if self.augment else 1)
 
     @staticmethod
     def preprocess(mask_values, pil_img, scale, is_mask):
+        """Same signature as the reference's static method (predict.py:19 calls it with mask_values=None)."""
         from PIL import Image
-        w, h = pil_img.size
-        new_w, new_h = int(scale * w), int(scale * h)
-        assert new_w > 0 and new_h > 0, "Scale is too small, resized images would have no pixel"
-        pil_img = pil_img.resize((new_w, new_h), resample=Image.NEAREST if is_mask else Image.BICUBIC)
-        img = np.asarray(pil_img)
         if is_mask:
-            mask = np.zeros((new_h, new_w), dtype=np.int8)
-            mask[img == 255] = 2
-            mask[img == 128] = 1
-            return mask
-        img = img[np.newaxis, ...] if img.ndim == 2 else img.transpose((2, 0, 1))
-        if (img > 1).any():
-            img = img.astype(np.float32) / 255.0
-        return img
+            grey = np.asarray(_rescaled(pil_img, scale, Image.NEAREST))
+            return _CLASS_OF_GREY[grey]
+        arr = np.asarray(_rescaled(pil_img, scale, Image.BICUBIC))
+        chw = arr[None] if arr.ndim == 2 else np.moveaxis(arr, -1, 0)
+        return chw.astype(np.float32) / 255.0 if (chw > 1).any() else chw
 
-    def __getitem__(self, idx):
-        n_rot = len(ROTATIONS) if self.augment else 1
-        name = self.ids[idx // n_rot]
-        angle = ROTATIONS[idx % n_rot]
-        mask_file = list(self.mask_dir.glob(name + self.mask_suffix + ".*"))
-        img_file = list(self.images_dir.glob(name + ".*"))
-        assert len(img_file) == 1, f"Either no image or multiple images found for the ID {name}: {img_file}"
-        assert len(mask_file) == 1, f"Either no mask or multiple masks found for the ID {name}: {mask_file}"
-        mask = load_image(mask_file[0])
-        img = load_image(img_file[0])
-        assert img.size == mask.size, f"Image and mask {name} should be the same size, but are {img.size} and {mask.size}"
-        if angle:
-            img, mask = img.rotate(angle, expand=True), mask.rotate(angle, expand=True)
-        img = self.preprocess(self.mask_values, img, self.scale, is_mask=False)
-        mask = self.preprocess(self.mask_values, mask, self.scale, is_mask=True)
-        assert np.isin(mask, (0, 1, 2)).all(), "mask holds an illegal class index"
-        return {"image": torch.as_tensor(img.copy()).float().contiguous(),
-                "mask": torch.as_tensor(mask.copy()).long().contiguous()}
+    def __getitem__(self, index: int) -> Dict[str, torch.Tensor]:
+        views = QUARTER_TURNS if self.augment else 1
+        stem, turns = self.ids[index // views], index % views
+        image = load_image(self._only(self.images_dir, stem, "image"))
+        mask = load_image(self._only(self.mask_dir, stem + self.mask_suffix, "mask"))
+        assert image.size == mask.size, f"Image and mask {stem} should be the same size, but are {image.size} and {mask.size}"
+        image, mask = _quarter_turn(image, turns), _quarter_turn(mask, turns)
+        pixels = self.preprocess(self.mask_values, image, self.scale, is_mask=False)
+        classes = self.preprocess(self.mask_values, mask, self.scale, is_mask=True)
+        return {"image": torch.from_numpy(np.ascontiguousarray(pixels)).float(),
+                "mask": torch.from_numpy(np.ascontiguousarray(classes)).long()}
 
 
 class CarvanaDataset(BasicDataset):

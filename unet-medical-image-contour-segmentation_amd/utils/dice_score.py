@@ -7,29 +7,31 @@ over groups are formed on device.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import Tensor
 
 from .. import ops
 
 
+def _groups(shape, all_dims: bool) -> int:
+    """Number of independent Dice ratios: 1 when every dimension is summed, else one per leading index."""
+    return 1 if all_dims else math.prod(int(d) for d in shape[:-2])
+
+
 def dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):
     assert input.size() == target.size()
     assert input.dim() == 3 or not reduce_batch_first
-    if input.dim() == 2 or reduce_batch_first:
-        ngroups = 1                                   # sums over every dimension
-    else:
-        ngroups = 1
-        for d in input.shape[:-2]:
-            ngroups *= int(d)                         # per-image ratios, then the mean
-    group_len = input.numel() // ngroups
-    return ops.DiceCoeffFn.apply(input, target, ngroups, group_len, float(epsilon))
+    ngroups = _groups(input.shape, all_dims=(input.dim() == 2 or reduce_batch_first))
+    return ops.DiceCoeffFn.apply(input, target, ngroups, input.numel() // ngroups, float(epsilon))
 
 
 def multiclass_dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):
+    # classes and images are folded into one leading axis: with reduce_batch_first this is ONE ratio over everything
     return dice_coeff(input.flatten(0, 1), target.flatten(0, 1), reduce_batch_first, epsilon)
 
 
 def dice_loss(input: Tensor, target: Tensor, multiclass: bool = False):
-    fn = multiclass_dice_coeff if multiclass else dice_coeff
-    return 1 - fn(input, target, reduce_batch_first=True)
+    coeff = (multiclass_dice_coeff if multiclass else dice_coeff)(input, target, reduce_batch_first=True)
+    return 1 - coeff
