@@ -81,6 +81,20 @@ size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt)
 int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
                      const void* x1, int C1, int ld1, float* dw_krsc, int Cout,
                      void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
+/* Narrow-tensor forms for the small-width models (UNet_S / UNet_T, unet_model.py:52-126: 8..64-channel layers).  The
+ * layer is COMPUTED as the next 64-aligned layer (filters zero-padded to C0 + C1 -> Cout, all multiples of 64, so the MFMA
+ * kernels apply), but the tensors in HBM hold only their first C0v / C1v / Coutv channels per pixel (multiples of one
+ * 16-byte piece: 8 bf16 / 4 fp32; ld* >= the valid count): channels beyond the valid count are read as zeros and never
+ * written.  stat_partials / scale / shift are sized for the padded Cout.  fwd: scale == shift == NULL stores the raw conv
+ * output (training, + optional statistics); otherwise the inference form z = max(conv*scale + shift, 0).
+ * wgrad: dw_krsc is the padded [Cout][3][3][C0 + C1] gradient (rows / columns of padding come out 0); workspace from
+ * uh_conv3x3_wgrad_ws_bytes of the padded shape.  Shapes outside the MFMA path return UH_EINVAL. */
+int uh_conv3x3_fwd_narrow(const void* x0, int C0, int C0v, int ld0, const void* x1, int C1, int C1v, int ld1,
+                          const void* w, void* y, int ldy, int Cout, int Coutv, float* stat_partials,
+                          const float* scale, const float* shift, int B, int H, int W, int dt, uh_stream stream);
+int uh_conv3x3_wgrad_narrow(const void* dy, int lddy, int Cout, int Coutv, const void* x0, int C0, int C0v, int ld0,
+                            const void* x1, int C1, int C1v, int ld1, float* dw_krsc, void* ws, size_t ws_bytes,
+                            int B, int H, int W, int dt, uh_stream stream);
 
 /* ---- nn.BatchNorm2d + nn.ReLU(inplace)  (unet_parts.py:16-17,19-20) ------------------------
  * finalize: merge the conv's stat slabs (Chan's formula, double) -> mean, rstd = 1/sqrt(var_biased + eps),

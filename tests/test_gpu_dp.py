@@ -140,5 +140,10 @@ def test_sync_bn_data_parallel_equals_single_process():
         assert gerr < 1e-3, f"gradient rel L2 {gerr:.3e}"
         assert uerr < 2e-2 and perr < 1.5e-4, f"update rel L2 {uerr:.3e}, max abs diff {perr:.3e}"
         for k, v in ref_run.items():
-            assert torch.allclose(run[k], v, rtol=1e-4, atol=1e-6), k
+            if k.endswith("running_mean"):      # a mean is known to a fraction of the data's spread, not of its own size
+                std = ref_run[k.replace("running_mean", "running_var")].sqrt()
+                err = float(((run[k] - v).abs() / (1e-4 * std + 1e-6)).max())
+            else:
+                err = float(((run[k] - v).abs() / (1e-4 * v.abs() + 1e-6)).max())
+            assert err <= 1.0, f"{k}: {err:.2f} x tolerance"
     assert (res[0][2] == res[1][2]).all()

@@ -454,3 +454,123 @@ def test_conv_transpose_bf16x3(B, h, w, Cin, Ho, Wo):
     assert _rel(y.permute(0, 3, 1, 2), ref.detach()) < 1e-4
     assert _rel(xg.grad.permute(0, 3, 1, 2), dxr) < 1e-4
     assert _rel(wg.grad, dwr) < 1e-4 and _rel(bg.grad, dbr) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# small-width layers (UNet_S / UNet_T): narrow tensors in HBM, arithmetic padded to 64 channels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 20, 28, 3, 0, 16), (2, 17, 23, 16, 16, 32), (1, 24, 24, 32, 0, 16),
+                                              (2, 16, 16, 64, 64, 32), (2, 12, 12, 128, 0, 8), (1, 9, 7, 1, 0, 8),
+                                              (2, 33, 18, 8, 8, 8), (1, 16, 16, 32, 32, 64)])
+def test_small_width_narrow_tensors(dtype, B, H, W, C0, C1, Cout):
+    """ConvBnReluNarrowFn (tensors at their real channel count, uh_conv3x3_*_narrow) against (a) the zero-padded 64-channel
+    formulation on the ordinary entry points -- same arithmetic, so the forward must agree BIT FOR BIT -- and (b) fp64
+    stock-PyTorch maths of conv -> BatchNorm(train) -> ReLU."""
+    import torch.nn as nn
+    from unet_amd import ops
+    from unet_amd.unet import unet_parts
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H * 7 + C0 * 13 + C1 * 17 + Cout)
+    Cin = C0 + C1
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1, bias=False)
+    bn = nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5))
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.2)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    gz = torch.randn(B, H, W, Cout, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    conv, bn = conv.to(dev), bn.to(dev)
+
+    def run(narrow, training=True):
+        ops.NARROW_IO = narrow
+        try:
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+            x0 = x[..., :C0].to(dev, dtype).contiguous().requires_grad_(True)
+            x1 = x[..., C0:].to(dev, dtype).contiguous().requires_grad_(True) if C1 else None
+            z = unet_parts._conv_bn_relu(x0, x1, conv, bn, training)
+            if not training:
+                return z.detach().float().cpu()
+            ins = [t for t in (x0, x1, conv.weight, bn.weight, bn.bias) if t is not None]
+            grads = torch.autograd.grad((z.float() * gz.to(dev)).sum(), ins)
+            out = [z.detach()] + list(grads) + [bn.running_mean.clone(), bn.running_var.clone()]
+            assert int(bn.num_batches_tracked) == 1
+            return [t.float().cpu() for t in out]
+        finally:
+            ops.NARROW_IO = True
+
+    nar, pad = run(True), run(False)
+    assert nar[0].shape == (B, H, W, Cout)
+    stem = Cin <= 4          # the padded formulation of an image layer runs on the (non-MFMA) stem kernels: same maths,
+    ftol = 1e-5 if dtype == torch.float32 else 2e-2     # another summation order
+
+    def same(a, b, what):
+        if stem:
+            e = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+            assert e < ftol, f"{what}: {e:.3e}"
+        else:
+            assert torch.equal(a, b), f"{what} differs from the padded formulation"
+
+    same(nar[0], pad[0], "forward")
+    same(nar[-2], pad[-2], "running_mean")
+    same(nar[-1], pad[-1], "running_var")
+    for a, b, name in zip(nar[1:-2], pad[1:-2], ["dx0", "dx1", "dW", "dgamma", "dbeta"] if C1 else ["dx0", "dW", "dgamma", "dbeta"]):
+        assert a.shape == b.shape, name
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert e < (1e-4 if dtype == torch.float32 else 2e-2), f"{name}: {e:.3e}"
+    # inference form (running statistics, fused scale/shift/ReLU epilogue)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1); bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+        rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+
+        def run_eval(narrow):
+            ops.NARROW_IO = narrow
+            try:
+                bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+                x0 = x[..., :C0].to(dev, dtype).contiguous()
+                x1 = x[..., C0:].to(dev, dtype).contiguous() if C1 else None
+                return unet_parts._conv_bn_relu(x0, x1, conv, bn, False).float().cpu()
+            finally:
+                ops.NARROW_IO = True
+        ze_n, ze_p = run_eval(True), run_eval(False)
+        same(ze_n, ze_p, "eval forward")
+        assert torch.equal(bn.running_mean, rm) and torch.equal(bn.running_var, rv)
+
+    if dtype == torch.float32:
+        xd = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+        wd = conv.weight.detach().double().cpu().requires_grad_(True)
+        gd = bn.weight.detach().double().cpu().requires_grad_(True)
+        bd = bn.bias.detach().double().cpu().requires_grad_(True)
+        zr = F.relu(F.batch_norm(F.conv2d(xd, wd, padding=1), None, None, gd, bd, True, 0.1, bn.eps))
+        ref = torch.autograd.grad((zr * gz.permute(0, 3, 1, 2).double()).sum(), [xd, wd, gd, bd])
+        assert _rel(nar[0].permute(0, 3, 1, 2), zr.detach()) < 1e-4
+        dx = torch.cat([nar[1], nar[2]], dim=-1) if C1 else nar[1]
+        k = 3 if C1 else 2
+        assert _rel(dx.permute(0, 3, 1, 2), ref[0]) < 2e-4
+        assert _rel(nar[k], ref[1]) < 2e-4
+        assert _rel(nar[k + 1], ref[2]) < 2e-4 and _rel(nar[k + 2], ref[3]) < 2e-4
+        ze_ref = F.relu(F.batch_norm(F.conv2d(xd.detach(), wd.detach(), padding=1), rm.double().cpu(), rv.double().cpu(),
+                                     gd.detach(), bd.detach(), False, 0.1, bn.eps))
+        assert _rel(ze_n.permute(0, 3, 1, 2), ze_ref) < 1e-4
+
+
+def test_narrow_entry_points_reject_bad_arguments():
+    from unet_amd import ops
+    from unet_amd._lib import LIB, UH_BF16
+    dev = _dev()
+    x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(64 * 9 * 64, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(RuntimeError):      # valid count not a multiple of a 16-byte piece
+        LIB.call("uh_conv3x3_fwd_narrow", x.data_ptr(), 64, 12, 16, None, 0, 0, 0, w.data_ptr(), y.data_ptr(), 16, 64, 16,
+                 None, None, None, 1, 8, 8, UH_BF16, st)
+    with pytest.raises(RuntimeError):      # padded count not on the MFMA path
+        LIB.call("uh_conv3x3_fwd_narrow", x.data_ptr(), 48, 16, 16, None, 0, 0, 0, w.data_ptr(), y.data_ptr(), 16, 64, 16,
+                 None, None, None, 1, 8, 8, UH_BF16, st)
+    with pytest.raises(RuntimeError):      # valid > padded
+        LIB.call("uh_conv3x3_fwd_narrow", x.data_ptr(), 64, 128, 16, None, 0, 0, 0, w.data_ptr(), y.data_ptr(), 16, 64, 16,
+                 None, None, None, 1, 8, 8, UH_BF16, st)

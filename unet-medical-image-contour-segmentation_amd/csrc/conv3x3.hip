@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes,
-    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift) {
+    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv) {
+    // C0 / C1 / Cout are the channel counts the filter pack is laid out for (multiples of a chunk / of 64); C0v / C1v /
+    // Coutv (<=) are the channels that exist in memory ("narrow" tensors of the small-width nets): input channels
+    // beyond them are fetched as zeros by the DMA, output channels beyond Coutv are computed (zero filters) but not stored.
     constexpr int ES = sizeof(T);
     constexpr int CK = 64 / ES;
     constexpr int VEC = 16 / ES;
@@ -491,11 +494,13 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         const bool first = cc < C0;
         const int ld = first ? ld0 : ld1;
         const int soff = (first ? cc : cc - C0) * ES;
+        const int cleft = first ? (C0v - cc) : (C1v - (cc - C0));      // channels of this chunk that exist in memory
         typedef __attribute__((address_space(3))) void* lds_ptr;
         unsigned char* dst = lds + bufi * HALO2_BYTES + wave * 1024;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            unsigned voff = pix[k] >= 0 ? (unsigned)((pix[k] >> 2) * ld * ES + (pix[k] & 3) * 16) : OOB_OFFSET;
+            unsigned voff = (pix[k] >= 0 && (pix[k] & 3) * VEC < cleft) ? (unsigned)((pix[k] >> 2) * ld * ES + (pix[k] & 3) * 16)
+                                                                        : OOB_OFFSET;
             if (k < NLOAD - 1 || tid + k * 256 < NPIECE) {
                 if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 for (int p = tid; p < RP * TILE * PPR; p += 256) {
                     const int px = p / PPR, part = p - px * PPR;
                     const int gy = y0 + r0 + (px >> 4), gxx = x0p + (px & 15);
-                    if (gy < H && gxx < W) {
+                    if (gy < H && gxx < W && co_blk + part * VEC < Coutv) {
                         u32x4 v = *reinterpret_cast<const u32x4*>(ob + px * PITCH + part * 16);
                         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y + (int64_t)((b * H + gy) * W + gxx) * ldy + co_blk) + part * 16) = v;
                     }
@@ -1148,7 +1153,10 @@ extern "C" int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int
 template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
-                                const float* ep_shift, bool* ep_done, bool split = false) {
+                                const float* ep_shift, bool* ep_done, bool split = false, int C0v = -1, int C1v = -1,
+                                int Coutv = -1) {
+    const bool narrow = C0v >= 0;          // narrow tensors: only the LDS-DMA MFMA kernel implements the channel masks
+    if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
     // runs the separate scale/shift/ReLU pass
     *ep_done = false;
@@ -1180,25 +1188,26 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
             *ep_done = ep_scale != nullptr;
             return UH_OK;
         }
         if (split) { uh_set_error("conv3x3_fwd: bf16x3 is implemented for tensors below 2 GiB only"); return UH_EINVAL; }
+        if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors are implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (Cout % 128 == 0) {
             hipLaunchKernelGGL((conv3x3_fwd_mfma<T, 4>), dim3(ntile, Cout / 128), dim3(256), 0, st, x0, C0, ld0, x1, C1,
                                ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY);
@@ -1210,6 +1219,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         return UH_OK;
     }
     if (split) { uh_set_error("conv3x3_fwd: bf16x3 needs an MFMA-aligned shape (Cin %% 16 == 0, Cout %% 64 == 0, 16-byte strides)"); return UH_EINVAL; }
+    if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors need padded counts that are MFMA-aligned and 16-byte strides"); return UH_EINVAL; }
     if (Cin <= 4 && C1 == 0) {
         constexpr int V = 16 / ES;
         if constexpr (ES == 2) {
@@ -1291,6 +1301,35 @@ extern "C" int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const
     return uh_bn_relu_apply(z, ldz, scale, shift, z, ldz, (int64_t)B * H * W, Cout, dt == UH_BF16 ? UH_BF16 : UH_F32, stream);
 }
 
+// Narrow tensors (small-width nets: 8..32 channels): the filter pack and the K loop use channel counts rounded up to the
+// MFMA granularity (C0 / C1 multiples of a 64-byte chunk, Cout multiple of 64) while x0 / x1 / y hold only C0v / C1v /
+// Coutv channels (multiples of a 16-byte piece) at their own pixel strides: nothing padded ever reaches HBM.
+// scale == NULL: plain forward (+ statistics, Cout columns per slab row); else the fused inference epilogue.
+extern "C" int uh_conv3x3_fwd_narrow(const void* x0, int C0, int C0v, int ld0, const void* x1, int C1, int C1v, int ld1,
+                                     const void* w, void* y, int ldy, int Cout, int Coutv, float* stat_partials,
+                                     const float* scale, const float* shift, int B, int H, int W, int dt, uh_stream stream) {
+    UH_REQUIRE(x0 && w && y, "uh_conv3x3_fwd_narrow: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd_narrow: bad shape");
+    UH_REQUIRE(C0v > 0 && C0v <= C0 && C1v >= 0 && C1v <= C1 && Coutv > 0 && Coutv <= Cout, "uh_conv3x3_fwd_narrow: bad valid counts");
+    UH_REQUIRE(ld0 >= C0v && ldy >= Coutv && (C1 == 0 || (x1 && ld1 >= C1v)), "uh_conv3x3_fwd_narrow: bad strides");
+    UH_REQUIRE((scale == nullptr) == (shift == nullptr), "uh_conv3x3_fwd_narrow: scale and shift come together");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd_narrow: pixel count overflows int32");
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_fwd_narrow: bad dtype %d", dt);
+    const int vec = dt == UH_BF16 ? 8 : 4;
+    UH_REQUIRE(C0v % vec == 0 && C1v % vec == 0 && Coutv % vec == 0, "uh_conv3x3_fwd_narrow: valid counts must be multiples of a 16-byte piece");
+    hipStream_t st = (hipStream_t)stream;
+    bool done = false;
+    int rc;
+    if (dt == UH_BF16)
+        rc = conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w, (bf16_t*)y,
+                                          ldy, Cout, stat_partials, B, H, W, st, scale, shift, &done, false, C0v, C1v, Coutv);
+    else
+        rc = conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)y, ldy,
+                                         Cout, stat_partials, B, H, W, st, scale, shift, &done, dt == UH_F32X3, C0v, C1v, Coutv);
+    if (rc != UH_OK || !scale || done) return rc;
+    return uh_bn_relu_apply(y, ldy, scale, shift, y, ldy, (int64_t)B * H * W, Coutv, dt == UH_BF16 ? UH_BF16 : UH_F32, stream);
+}
+
 // =====================================================================================
 // backward-weights, MFMA.  Workgroup = (64 out-ch) x (64 in-ch) x 9 taps over a range of pixel tiles.
 // Wave (wr, wc) owns a 32x32 (co, ci) block for all 9 taps: 9 x 16 = 144 accumulator registers.
@@ -1313,7 +1352,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
-    int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit) {
+    int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
+    int C0v, int C1v, int Coutv) {              // channels that exist in memory (narrow tensors), see conv3x3_fwd_mfma_v2
     constexpr int ES = sizeof(T);
     constexpr int TH = WgradCfg<T>::TH;
     constexpr int PB = 64 * ES;                 // bytes per pixel in LDS (64 channels)
@@ -1332,8 +1372,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
     const int cot = blockIdx.y / nci, cit = blockIdx.y - cot * nci;
     const int co0 = cot * 64, ci0 = cit * 64;
     const T* xsrc; int ldx;
-    if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; }
+    int xleft;                                   // channels of this 64-channel input slab that exist in memory
+    if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; xleft = C0v - ci0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; xleft = C1v - (ci0 - C0); }
     const T* dsrc = dy + co0;
+    const int dleft = Coutv - co0;
 
     const int ntile = B * tilesX * tilesY;
     const int split = blockIdx.x;
@@ -1365,7 +1407,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
             int hy = q / HALO_W, hx = q - hy * HALO_W;
             int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W && part * VEC < xleft)
                 v = *reinterpret_cast<const u32x4*>(xsrc + (int64_t)((b * H + gy) * W + gx) * ldx + part * VEC);
             *reinterpret_cast<u32x4*>(xs + lds_addr(q, part * 16)) = v;
         }
@@ -1374,7 +1416,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
             int ty = q / TILE, tx = q - ty * TILE;
             int gy = y0 + ty, gx = x0p + tx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (gy < H && gx < W)
+            if (gy < H && gx < W && part * VEC < dleft)
                 v = *reinterpret_cast<const u32x4*>(dsrc + (int64_t)((b * H + gy) * W + gx) * lddy + part * VEC);
             *reinterpret_cast<u32x4*>(ds + lds_addr(q, part * 16)) = v;
         }
@@ -1547,7 +1589,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
-    unsigned dy_bytes, unsigned x_bytes) {
+    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv) {
     static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
     constexpr int TH = 8;
     constexpr int PB = 128;                     // bytes per pixel: 64 bf16 channels
@@ -1566,7 +1608,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     const int cot = blockIdx.y / nci, cit = blockIdx.y - cot * nci;
     const int co0 = cot * 64, ci0 = cit * 64;
     const T* xsrc; int ldx;
-    if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; }
+    int xleft;                                   // channels of this slab that exist in memory (narrow tensors)
+    if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; xleft = C0v - ci0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; xleft = C1v - (ci0 - C0); }
+    const int dleft = Coutv - co0;
     __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc, 0, (int)x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)dy_bytes, 0x00020000);
 
@@ -1584,14 +1628,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         const int q = p >> 3;
         const int hy = q / HALO_W, hx = q - hy * HALO_W;
         const int u = (p & 7) ^ (((hx >> 1) & 1) << 2);          // swizzle by halo COLUMN: row independent
-        xg[k] = (p < XUNITS) ? ((hy << 8) | hx) : -1;
+        xg[k] = (p < XUNITS && u * 8 < xleft) ? ((hy << 8) | hx) : -1;       // units beyond the valid channels read as zeros
         xo[k] = (hy * W + hx) * ldx * 2 + u * 16;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = tid + k * 256;
         const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
-        dg[k] = ((q >> 4) << 8) | (q & 15);
+        dg[k] = (u * 8 < dleft) ? (((q >> 4) << 8) | (q & 15)) : -1;
         dof[k] = ((q >> 4) * W + (q & 15)) * lddy * 2 + u * 16;
     }
     auto issue = [&](int tile, int bufi) {
@@ -1609,12 +1653,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
             const int gy = y0 - 1 + (xg[k] >> 8), gx = x0p - 1 + (xg[k] & 255);
             const bool ok = xg[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
             unsigned voff = ok ? (unsigned)(xbase + xo[k]) : OOB_OFFSET;
-            if (k < 5 || xg[k] >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
+            if (k < 5 || tid + k * 256 < XUNITS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gy = y0 + (dg[k] >> 8), gx = x0p + (dg[k] & 255);
-            const bool ok = gy < H && gx < W;
+            const bool ok = dg[k] >= 0 && gy < H && gx < W;
             unsigned voff = ok ? (unsigned)(dbase + dof[k]) : OOB_OFFSET;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(db + k * 4096), 16, voff, 0, 0, 0);
         }
@@ -1991,13 +2035,19 @@ extern "C" size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
 template <typename T>
 static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, int ld0, const T* x1, int C1, int ld1,
                                   float* dw, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, hipStream_t st,
-                                  bool split = false) {
+                                  bool split = false, int C0v = -1, int C1v = -1, int Coutv = -1) {
     constexpr int ES = sizeof(T);
     const int Cin = C0 + C1;
+    const bool narrow = C0v >= 0;                 // tensors hold fewer channels than the filter is padded to
+    if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     const bool aligned = uh_aligned16(dy) && uh_aligned16(x0) && (C1 == 0 || uh_aligned16(x1)) && (lddy * ES) % 16 == 0 &&
                          (ld0 * ES) % 16 == 0 && (C1 == 0 || (ld1 * ES) % 16 == 0) && (C0 % 64 == 0);
     WgradPlan p = wgrad_plan<T>(B, H, W, Cin, Cout, aligned);
     if (p.kind == 1 && C1 != 0) p.kind = 2;
+    if (narrow && p.kind != 0) {
+        uh_set_error("uh_conv3x3_wgrad_narrow: needs the MFMA path (padded channel counts multiples of 64, 16-byte strides)");
+        return UH_EINVAL;
+    }
     if (split && p.kind != 0) {
         uh_set_error("uh_conv3x3_wgrad: bf16x3 needs an MFMA-aligned shape (channel counts multiples of 64, 16-byte strides)");
         return UH_EINVAL;
@@ -2024,7 +2074,8 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
                 // byte extents of the (sliced) source views as seen from their base pointers
                 unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
                 hipLaunchKernelGGL(conv3x3_wgrad_mfma_v2<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
-                                   lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb);
+                                   lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb, C0v,
+                                   C1v, Coutv);
                 UH_CHECK_LAUNCH("conv3x3_wgrad_mfma_v2");
             }
         }
@@ -2032,10 +2083,11 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             if (split) {
                 if constexpr (ES == 4)
                     hipLaunchKernelGGL((conv3x3_wgrad_mfma<T, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
-                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, C0v,
+                                       C1v, Coutv);
             } else
                 hipLaunchKernelGGL(conv3x3_wgrad_mfma<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy, lddy,
-                                   x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit);
+                                   x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, C0v, C1v, Coutv);
             UH_CHECK_LAUNCH("conv3x3_wgrad_mfma");
         }
     } else {
@@ -2085,4 +2137,25 @@ extern "C" int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0
                                               ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st);
     return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
                                          dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3);
+}
+
+// Narrow variant (see uh_conv3x3_fwd_narrow): the filter gradient is that of the PADDED layer [Cout][3][3][C0 + C1]; x0 / x1 /
+// dy hold only their first C0v / C1v / Coutv channels per pixel, the rest count as zeros (their dW rows come out 0).
+extern "C" int uh_conv3x3_wgrad_narrow(const void* dy, int lddy, int Cout, int Coutv, const void* x0, int C0, int C0v, int ld0,
+                                       const void* x1, int C1, int C1v, int ld1, float* dw_krsc, void* ws, size_t ws_bytes,
+                                       int B, int H, int W, int dt, uh_stream stream) {
+    UH_REQUIRE(dy && x0 && dw_krsc, "uh_conv3x3_wgrad_narrow: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_wgrad_narrow: bad shape");
+    UH_REQUIRE(C0v > 0 && C0v <= C0 && C1v >= 0 && C1v <= C1 && Coutv > 0 && Coutv <= Cout, "uh_conv3x3_wgrad_narrow: bad valid counts");
+    UH_REQUIRE(lddy >= Coutv && ld0 >= C0v && (C1 == 0 || (x1 && ld1 >= C1v)), "uh_conv3x3_wgrad_narrow: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_wgrad_narrow: pixel count overflows int32");
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_wgrad_narrow: bad dtype %d", dt);
+    const int vec = dt == UH_BF16 ? 8 : 4;
+    UH_REQUIRE(C0v % vec == 0 && C1v % vec == 0 && Coutv % vec == 0, "uh_conv3x3_wgrad_narrow: valid counts must be multiples of a 16-byte piece");
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == UH_BF16)
+        return conv3x3_wgrad_dispatch<bf16_t>((const bf16_t*)dy, lddy, (const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1,
+                                              ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st, false, C0v, C1v, Coutv);
+    return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
+                                         dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3, C0v, C1v, Coutv);
 }

@@ -527,6 +527,196 @@ class ConvBnReluFn(Function):
         return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- small-width conv + BN + ReLU
+# Small-width layers keep their activations at the real channel count in HBM (False: 64-channel zero-padded tensors, the
+# first implementation -- kept for A/B measurements and as the path for channel counts that are not 16-byte multiples).
+NARROW_IO = True
+
+
+def _rup64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+def narrow_ok(x0: torch.Tensor, x1: Optional[torch.Tensor], Cout: int) -> bool:
+    """Can this layer run on the narrow-tensor conv entry points?  (every stored channel count a multiple of one
+    16-byte piece, 16-byte aligned pixel rows)"""
+    vec = 16 // x0.element_size()
+    for t in (x0, x1):
+        if t is None:
+            continue
+        if t.shape[-1] % vec or (pixel_ld(t) * t.element_size()) % 16 or t.data_ptr() % 16:
+            return False
+    return Cout % vec == 0
+
+
+class ConvBnReluNarrowFn(Function):
+    """(Conv2d 3x3 -> BatchNorm2d -> ReLU) of unet_parts.py:15-20 for the small-width models (UNet_S / UNet_T,
+    unet_model.py:52-126): COMPUTED as the next 64-aligned layer -- zero filters / unit gamma in the padding, so the
+    MFMA kernels of the full-width UNet apply -- while every activation in HBM (x, raw conv output, z and their
+    gradients) keeps its real channel count: the conv kernels read channels beyond the stored count as zeros and never
+    write them (uh_conv3x3_fwd_narrow / uh_conv3x3_wgrad_narrow).  `c0_true`: x0 may itself carry zero channels up to
+    a 16-byte piece (the 1- or 3-channel input image); only its first c0_true channels meet filter taps."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
+                training: bool, momentum: float, eps: float, c0_true: int):
+        _require_gpu(x0, "activation")
+        x0 = dense_nhwc(x0)
+        x1 = None if x1 is None else dense_nhwc(x1)
+        B, H, W, C0m = x0.shape
+        C1m = 0 if x1 is None else x1.shape[3]
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if Cin != c0_true + C1m or c0_true > C0m:
+            raise RuntimeError(f"conv expects {Cin} input channels, got {c0_true}+{C1m}")
+        if not narrow_ok(x0, x1, Cout):
+            raise RuntimeError("narrow conv: stored channel counts / strides must be multiples of 16 bytes")
+        Cp0, Cp1, Cop = _rup64(C0m), _rup64(C1m) if C1m else 0, _rup64(Cout)
+        Cinp = Cp0 + Cp1
+        dev = x0.device
+        need_dx = (ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1])
+        cdt = conv_dt(x0, Cp0, Cp1, Cop, any(need_dx) and training)
+        with torch.no_grad():
+            w32 = weight if weight.dtype == torch.float32 else weight.float()
+            wp = torch.zeros(Cop, Cinp, 3, 3, dtype=torch.float32, device=dev)
+            wp[:Cout, :c0_true] = w32[:, :c0_true]
+            if C1m:
+                wp[:Cout, Cp0:Cp0 + C1m] = w32[:, c0_true:]
+            gp = torch.ones(Cop, dtype=torch.float32, device=dev)
+            gp[:Cout] = gamma
+            bp = torch.zeros(Cop, dtype=torch.float32, device=dev)
+            bp[:Cout] = beta
+            rm = rv = None
+            if running_mean is not None:
+                rm = torch.zeros(Cop, dtype=torch.float32, device=dev)
+                rm[:Cout] = running_mean
+                rv = torch.ones(Cop, dtype=torch.float32, device=dev)
+                rv[:Cout] = running_var
+        single = x1 is None
+        wf, wd0 = pack_w3x3(wp, x0.dtype, training and need_dx[0] and single, cdt)
+        wd1 = None
+        if training and not single:
+            # backward-data runs once per source (its own narrow dx): one flipped / transposed pack per channel block
+            wd0 = pack_w3x3(wp[:, :Cp0], x0.dtype, True, cdt)[1] if need_dx[0] else None
+            wd1 = pack_w3x3(wp[:, Cp0:], x0.dtype, True, cdt)[1] if need_dx[1] else None
+        coef = torch.empty(4 * Cop, dtype=torch.float32, device=dev)
+        scale, shift, mean, rstd = coef[:Cop], coef[Cop:2 * Cop], coef[2 * Cop:3 * Cop], coef[3 * Cop:]
+        n = B * H * W
+        ld0, ld1 = pixel_ld(x0), 0 if x1 is None else pixel_ld(x1)
+        flops = 2.0 * n * Cop * 9 * Cinp
+        if not training:
+            LIB.call("uh_bn_eval_coeffs", gp.data_ptr(), bp.data_ptr(), rm.data_ptr(), rv.data_ptr(), float(eps), Cop,
+                     scale.data_ptr(), shift.data_ptr(), _stream())
+            z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
+            with _Timed("conv3x3_fwd_narrow", flops):
+                LIB.call("uh_conv3x3_fwd_narrow", x0.data_ptr(), Cp0, C0m, ld0, _p(x1), Cp1, C1m, ld1, wf.data_ptr(),
+                         z.data_ptr(), Cout, Cop, Cout, None, scale.data_ptr(), shift.data_ptr(), B, H, W, cdt, _stream())
+            ctx.training = False
+            return z
+        y = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
+        nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cinp, Cop, cdt)
+        stats = torch.empty(nslab * (2 * Cop + 2), dtype=torch.float32, device=dev)
+        with _Timed("conv3x3_fwd_narrow", flops):
+            LIB.call("uh_conv3x3_fwd_narrow", x0.data_ptr(), Cp0, C0m, ld0, _p(x1), Cp1, C1m, ld1, wf.data_ptr(),
+                     y.data_ptr(), Cout, Cop, Cout, stats.data_ptr(), None, None, B, H, W, cdt, _stream())
+        nbt = num_batches_tracked
+        fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
+        nbt_ptr = nbt.data_ptr() if fused_nbt else None
+        n_total = n
+        if SYNC_BN is None:
+            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cop, n, gp.data_ptr(), bp.data_ptr(), _p(rm), _p(rv),
+                     nbt_ptr, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                     rstd.data_ptr(), None, _stream())
+        else:
+            m2 = torch.empty(Cop, dtype=torch.float32, device=dev)
+            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cop, n, gp.data_ptr(), bp.data_ptr(), None, None, None,
+                     float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                     m2.data_ptr(), _stream())
+            n_total = _sync_bn_forward(coef, m2, n, Cop, gp, bp, rm, rv, nbt_ptr, momentum, eps)
+        if nbt is not None and not fused_nbt:
+            nbt.add_(1)
+        if rm is not None:
+            with torch.no_grad():
+                running_mean.copy_(rm[:Cout])
+                running_var.copy_(rv[:Cout])
+        z = torch.empty_like(y)
+        LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout, n, Cout,
+                 _dt(y), _stream())
+        ctx.save_for_backward(x0, x1, y, coef, wd0, wd1, weight)
+        ctx.bn_params = (gamma, beta)
+        ctx.training = True
+        ctx.dims = (B, H, W, C0m, C1m, Cout, c0_true)
+        ctx.cdt = cdt
+        ctx.n_total = n_total
+        ctx.sync_bn = SYNC_BN if n_total != n else None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if not ctx.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not part of the train path")
+        x0, x1, y, coef, wd0, wd1, weight = ctx.saved_tensors
+        B, H, W, C0m, C1m, Cout, c0_true = ctx.dims
+        Cp0, Cp1, Cop = _rup64(C0m), _rup64(C1m) if C1m else 0, _rup64(Cout)
+        Cinp = Cp0 + Cp1
+        n = B * H * W
+        dev = y.device
+        dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
+        scale, shift, mean, rstd = coef[:Cop], coef[Cop:2 * Cop], coef[2 * Cop:3 * Cop], coef[3 * Cop:]
+        dt = _dt(y)
+        nblk = LIB.query("uh_bn_bwd_nblk", n, Cout)
+        partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
+        LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
+        gamma_p, beta_p = ctx.bn_params
+        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
+        dy = torch.empty_like(y)
+        if ctx.sync_bn is None:
+            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
+                     dbeta.data_ptr(), dy.data_ptr(), Cout, n, 0, Cout, dt, _stream())
+        else:
+            import torch.distributed as dist
+            LIB.call("uh_bn_bwd_finalize", partials.data_ptr(), nblk, Cout, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+            glob = torch.cat([dgamma.reshape(-1), dbeta.reshape(-1)])
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.sync_bn[0])
+            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, 0, glob[:Cout].data_ptr(),
+                     glob[Cout:].data_ptr(), dy.data_ptr(), Cout, n, ctx.n_total, Cout, dt, _stream())
+        # backward-data: the padded layer's transposed conv, once per source, each writing its own narrow dx
+        dx = [None, None]
+        for i, (wd, Cp, Cm) in enumerate(((wd0, Cp0, C0m), (wd1, Cp1, C1m))):
+            if wd is None or not ctx.needs_input_grad[i]:
+                continue
+            dx[i] = torch.empty(B, H, W, Cm, dtype=y.dtype, device=dev)
+            with _Timed("conv3x3_fwd_narrow", 2.0 * n * Cop * 9 * Cp):
+                LIB.call("uh_conv3x3_fwd_narrow", dy.data_ptr(), Cop, Cout, Cout, None, 0, 0, 0, wd.data_ptr(),
+                         dx[i].data_ptr(), Cm, Cp, Cm, None, None, None, B, H, W, ctx.cdt, _stream())
+        dweight = None
+        if ctx.needs_input_grad[2]:
+            wdt = UH_F32X3 if (ctx.cdt == UH_F32X3) else dt
+            nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cinp, Cop, dt)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dwk = torch.empty(Cop, 3, 3, Cinp, dtype=torch.float32, device=dev)
+            with _Timed("conv3x3_wgrad_narrow", 2.0 * n * Cop * 9 * Cinp):
+                LIB.call("uh_conv3x3_wgrad_narrow", dy.data_ptr(), Cout, Cop, Cout, x0.data_ptr(), Cp0, C0m, pixel_ld(x0),
+                         _p(x1), Cp1, C1m, 0 if x1 is None else pixel_ld(x1), dwk.data_ptr(), ws.data_ptr(), nbytes,
+                         B, H, W, wdt, _stream())
+            dweight, cb_w = _grad_buffer(weight)
+            dweight[:, :c0_true].copy_(dwk[:Cout, :, :, :c0_true].permute(0, 3, 1, 2))
+            if C1m:
+                dweight[:, c0_true:].copy_(dwk[:Cout, :, :, Cp0:Cp0 + C1m].permute(0, 3, 1, 2))
+            if cb_w is not None:
+                cb_w()
+                dweight = None
+        if cb_g is not None:
+            cb_g()
+            dgamma = None
+        if cb_b is not None:
+            cb_b()
+            dbeta = None
+        return dx[0], dx[1], dweight, dgamma, dbeta, None, None, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------- max-pool
 def _maxpool_fwd(x):
     B, H, W, C = x.shape

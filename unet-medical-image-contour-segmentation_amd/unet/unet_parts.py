@@ -38,10 +38,12 @@ def _pad_c(t, cpad: int):
 def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, keep_padded: bool = False,
                   x0_channels: int = None):
     """One (conv3x3 -> BatchNorm -> ReLU) layer.  Layers whose channel counts are not multiples of 64 (the small-width
-    UNet_S / UNet_T of unet_model.py:52-126) are run as the next larger 64-aligned layer with zero filters / unit gamma
-    in the padding, so that they use the same MFMA kernels as the full-width UNet instead of the generic scalar
-    kernels: padded input channels meet zero filter taps, padded output channels are exactly 0 before and after
-    BatchNorm+ReLU (mean 0, shift 0), and their gradients never reach a parameter (the slices below drop them).
+    UNet_S / UNet_T of unet_model.py:52-126) are computed as the next larger 64-aligned layer with zero filters / unit
+    gamma in the padding, so that they use the same MFMA kernels as the full-width UNet instead of the generic scalar
+    kernels.  Default (ops.NARROW_IO): the tensors themselves stay at their real channel count (ConvBnReluNarrowFn).
+    Otherwise / for channel counts that are not 16-byte multiples: zero-padded 64-channel tensors -- padded input
+    channels meet zero filter taps, padded output channels are exactly 0 before and after BatchNorm+ReLU (mean 0,
+    shift 0), and their gradients never reach a parameter (the slices below drop them).
     `x0_channels`: x0 is already such a padded tensor and only its first x0_channels channels are real.
     `keep_padded`: return the padded tensor (DoubleConv hands it to its second conv without a copy)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
@@ -57,6 +59,14 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
         z = ops.ConvBnReluFn.apply(x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    bn.num_batches_tracked, training, momentum, bn.eps)
         return z
+    if ops.NARROW_IO and x0_channels is None:
+        # tensors keep their real channel count in HBM, only the arithmetic is padded (ops.ConvBnReluNarrowFn); the
+        # 1- / 3-channel image is widened to one 16-byte piece so that it can be fetched like any other activation
+        vec = 16 // x0.element_size()
+        x0n = _pad_c(x0, (C0 + vec - 1) // vec * vec)
+        if ops.narrow_ok(x0n, x1, Cout):
+            return ops.ConvBnReluNarrowFn.apply(x0n, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                bn.num_batches_tracked, training, momentum, bn.eps, C0)
     x0p = x0 if x0_channels is not None else _pad_c(x0, Cp0)
     x1p = None if x1 is None else _pad_c(x1, Cp1)
     # filter [Cout, C0 + C1, 3, 3] -> [Cop, Cp0 + Cp1, 3, 3]: each source's channel block is padded separately
