@@ -268,26 +268,62 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
     __syncthreads();
     const int sub = threadIdx.x % LPP;
     const int ppb = 256 / LPP;
-    for (int64_t p = (int64_t)blockIdx.x * ppb + threadIdx.x / LPP; p < npix; p += (int64_t)gridDim.x * ppb) {
-        float acc[MAXCLS];
+    constexpr int U = 4;            // pixels per lane per trip: U independent 16-byte loads in flight (HBM-bound kernel)
+    const bool one_piece = Cin == LPP * V;      // the common case (64 channels): exactly one piece per lane and pixel
+    for (int64_t p0 = (int64_t)blockIdx.x * (U * ppb) + threadIdx.x / LPP; p0 < npix; p0 += (int64_t)gridDim.x * (U * ppb)) {
+        float acc[U][MAXCLS];
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) acc[k] = 0.f;
-        for (int c = sub * V; c < Cin; c += LPP * V) {
-            float v[V];
-            uh_load<T, V>(x + p * ldx + c, v);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) acc[u][k] = 0.f;
+        if (one_piece) {
+            float v[U][V];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * ppb;
+                if (p < npix) uh_load<T, V>(x + p * ldx + sub * V, v[u]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) v[u][i] = 0.f;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < MAXCLS; ++k)
                 if (k < ncls) {
 #pragma unroll
-                    for (int i = 0; i < V; ++i) acc[k] = fmaf(v[i], ws[k * Cin + c + i], acc[k]);
+                    for (int i = 0; i < V; ++i) {
+                        const float wk = ws[k * Cin + sub * V + i];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) acc[u][k] = fmaf(v[u][i], wk, acc[u][k]);
+                    }
                 }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * ppb;
+                if (p >= npix) continue;
+                for (int c = sub * V; c < Cin; c += LPP * V) {
+                    float v[V];
+                    uh_load<T, V>(x + p * ldx + c, v);
+#pragma unroll
+                    for (int k = 0; k < MAXCLS; ++k)
+                        if (k < ncls) {
+#pragma unroll
+                            for (int i = 0; i < V; ++i) acc[u][k] = fmaf(v[i], ws[k * Cin + c + i], acc[u][k]);
+                        }
+                }
+            }
         }
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k)
-            if (k < ncls) {
-                for (int o = LPP >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
-                if (sub == 0) logits[p * ncls + k] = acc[k] + bias[k];
-            }
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + (int64_t)u * ppb;
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k)
+                if (k < ncls) {
+                    for (int o = LPP >> 1; o > 0; o >>= 1) acc[u][k] += __shfl_xor(acc[u][k], o, 64);
+                    if (sub == 0 && p < npix) logits[p * ncls + k] = acc[u][k] + bias[k];
+                }
+        }
     }
 }
 
@@ -321,8 +357,9 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
     const int PL = 256 / GB;
     const int RW = GB * V + 1;
     const int gl = threadIdx.x % GB, pl = threadIdx.x / GB;
-    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    // Workgroups interleave over chunks of U*PL pixels (see bn_relu_bwd_reduce_kernel): neighbouring workgroups stream
+    // neighbouring addresses, and every lane keeps U independent 16-byte loads in flight.
+    constexpr int U = 4;
     for (int gb = 0; gb < G; gb += GB) {
         const int c = (gb + gl) * V;
         float acc[NC][V], bs[NC];
@@ -334,16 +371,30 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
         }
         const bool act = pl < PL && gb + gl < G;
         if (act)
-            for (int64_t p = p0 + pl; p < p1; p += PL) {
-                float xv[V];
-                uh_load<T, V>(x + p * ldx + c, xv);
+            for (int64_t p = (int64_t)blockIdx.x * (U * PL) + pl; p < npix; p += (int64_t)gridDim.x * (U * PL)) {
+                float xv[U][V], g[U][NC];
 #pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    float g = dl[p * NC + k];
-                    bs[k] += g;
+                for (int u = 0; u < U; ++u) {
+                    const int64_t q = p + (int64_t)u * PL;
+                    if (q < npix) {
+                        uh_load<T, V>(x + q * ldx + c, xv[u]);
 #pragma unroll
-                    for (int i = 0; i < V; ++i) acc[k][i] = fmaf(g, xv[i], acc[k][i]);
+                        for (int k = 0; k < NC; ++k) g[u][k] = dl[q * NC + k];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) xv[u][i] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) g[u][k] = 0.f;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        bs[k] += g[u][k];
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[k][i] = fmaf(g[u][k], xv[u][i], acc[k][i]);
+                    }
             }
         __syncthreads();
         if (act) {
@@ -388,8 +439,8 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
 }
 
 static int c11_nblk(int64_t npix) {
-    int64_t n = (npix + 4095) / 4096;
-    if (n > 512) n = 512;
+    int64_t n = (npix + 1023) / 1024;
+    if (n > 2048) n = 2048;
     if (n < 1) n = 1;
     return (int)n;
 }
