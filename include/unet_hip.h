@@ -88,7 +88,12 @@ int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
  * written.  stat_partials / scale / shift are sized for the padded Cout.  fwd: scale == shift == NULL stores the raw conv
  * output (training, + optional statistics); otherwise the inference form z = max(conv*scale + shift, 0).
  * wgrad: dw_krsc is the padded [Cout][3][3][C0 + C1] gradient (rows / columns of padding come out 0); workspace from
- * uh_conv3x3_wgrad_ws_bytes of the padded shape.  Shapes outside the MFMA path return UH_EINVAL. */
+ * uh_conv3x3_wgrad_ws_bytes of the padded shape.  Shapes outside the MFMA path return UH_EINVAL.
+ * uh_pack_w3x3_padded: uh_pack_w3x3 of the reference-layout filter [Cout][C0 + C1][3][3] into the padded layer
+ * [Coutp][Cp0 + Cp1] (source block 0 -> padded channels 0.., block 1 -> Cp0.., zeros elsewhere); the backward-data copy
+ * [Cp0 + Cp1][3][3][Coutp] holds the per-source filters as its row blocks (UH_F32 / UH_BF16). */
+int uh_pack_w3x3_padded(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int C0, int C1,
+                        int Coutp, int Cp0, int Cp1, void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
 int uh_conv3x3_fwd_narrow(const void* x0, int C0, int C0v, int ld0, const void* x1, int C1, int C1v, int ld1,
                           const void* w, void* y, int ldy, int Cout, int Coutv, float* stat_partials,
                           const float* scale, const float* shift, int B, int H, int W, int dt, uh_stream stream);
@@ -106,6 +111,12 @@ int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,
                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                    int64_t* num_batches_tracked, float momentum, float eps,
                    float* scale, float* shift, float* mean, float* rstd, float* m2_out, uh_stream stream);
+/* uh_bn_finalize over the first C channels of stat rows that are ldc >= C channels wide (small-width layers: the conv, and
+ * so its statistics, are laid out for the 64-aligned channel count, uh_conv3x3_fwd_narrow); per-channel arrays: C entries. */
+int uh_bn_finalize_ld(const float* stat_partials, int nslab, int ldc, int C, int64_t n,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps,
+                      float* scale, float* shift, float* mean, float* rstd, float* m2_out, uh_stream stream);
 /* eval mode: scale/shift from the running statistics. */
 int uh_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift,

@@ -25,7 +25,7 @@ __device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, dou
 // Rows with a zero pixel count are skipped (producers that use fewer rows than
 // the buffer holds zero the counts of the rest); the number of leading rows to walk is found first.  Chan merge in
 // double, then the affine coefficients, the running statistics and num_batches_tracked.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int C, double n,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int ldc, int C, double n,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __shared__ int last_row;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 16 + cl;
-    const float* cnt = stats + (int64_t)nslab * 2 * C;
+    const float* cnt = stats + (int64_t)nslab * 2 * ldc;      // ldc: channels per stat row (>= C)
     if (threadIdx.x == 0) last_row = -1;
     __syncthreads();
     int last = -1;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     if (c < C)
         for (int f = sl; f < R; f += 64) {
             const double nf = (double)cnt[f];
-            if (nf > 0.0) { a = fma(nf, (double)stats[((int64_t)f * 2 + 0) * C + c], a); cn += nf; }
+            if (nf > 0.0) { a = fma(nf, (double)stats[((int64_t)f * 2 + 0) * ldc + c], a); cn += nf; }
         }
     const double A = block_sum(a, 0), N = block_sum(cn, 1);
     const double mean = N > 0.0 ? A / N : 0.0;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         for (int f = sl; f < R; f += 64) {
             const double nf = (double)cnt[f];
             if (nf > 0.0) {
-                const double d = (double)stats[((int64_t)f * 2 + 0) * C + c] - mean;
-                q += (double)stats[((int64_t)f * 2 + 1) * C + c] + nf * d * d;
+                const double d = (double)stats[((int64_t)f * 2 + 0) * ldc + c] - mean;
+                q += (double)stats[((int64_t)f * 2 + 1) * ldc + c] + nf * d * d;
             }
         }
     Moments m = {N, mean, block_sum(q, 2)};
@@ -104,7 +104,24 @@ extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int6
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
     UH_REQUIRE(nslab > 0 && C > 0 && n > 0, "uh_bn_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, (double)n, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, C, (double)n, gamma,
+                       beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
+                       (long long*)num_batches_tracked, m2_out);
+    UH_CHECK_LAUNCH("bn_finalize_kernel");
+    return UH_OK;
+}
+
+// As uh_bn_finalize for the first C channels of stat rows that are ldc >= C channels wide (the conv of a small-width layer
+// is computed -- and its statistics are laid out -- for the 64-aligned channel count, uh_conv3x3_fwd_narrow): every
+// per-channel array here has C entries.
+extern "C" int uh_bn_finalize_ld(const float* stat_partials, int nslab, int ldc, int C, int64_t n, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                 float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                                 float* m2_out, uh_stream stream) {
+    UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize_ld: null pointer");
+    UH_REQUIRE(nslab > 0 && C > 0 && ldc >= C && n > 0, "uh_bn_finalize_ld: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, ldc, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
                        (long long*)num_batches_tracked, m2_out);
     UH_CHECK_LAUNCH("bn_finalize_kernel");

@@ -93,6 +93,47 @@ extern "C" int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, 
     return UH_OK;
 }
 
+// Zero-padded pack for the small-width layers (uh_conv3x3_fwd_narrow): the filter [Cout][C0 + C1][3][3] is packed as the
+// 64-aligned layer [Coutp][Cp0 + Cp1]: source block 0 (C0 channels) goes to padded channels 0.., block 1 (C1) to Cp0..;
+// everything else is zero.  Backward-data copy: [Cp0 + Cp1][3][3][Coutp], i.e. the per-source packs are its row blocks.
+template <typename T>
+__global__ void pack_w3x3_padded_kernel(const float* __restrict__ w, int64_t sO, int64_t sI, int64_t sH, int64_t sW,
+                                        int Cout, int C0, int C1, int Coutp, int Cp0, int Cp1, T* __restrict__ wf,
+                                        T* __restrict__ wd) {
+    const int Cinp = Cp0 + Cp1;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)Coutp * 9 * Cinp;
+    if (idx >= total) return;
+    int ip = (int)(idx % Cinp);
+    int t = (int)((idx / Cinp) % 9);
+    int o = (int)(idx / (9 * (int64_t)Cinp));
+    int r = t / 3, sx = t - 3 * r;
+    int ci = -1;
+    if (ip < Cp0) { if (ip < C0) ci = ip; }
+    else if (ip - Cp0 < C1) ci = C0 + (ip - Cp0);
+    float v = (o < Cout && ci >= 0) ? w[o * sO + ci * sI + r * sH + sx * sW] : 0.f;
+    wf[idx] = uh_from_f32<T>(v);
+    if (wd) wd[(((int64_t)ip * 3 + (2 - r)) * 3 + (2 - sx)) * Coutp + o] = uh_from_f32<T>(v);
+}
+
+extern "C" int uh_pack_w3x3_padded(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int C0, int C1,
+                                   int Coutp, int Cp0, int Cp1, void* w_fwd, void* w_dgrad, int dt, uh_stream stream) {
+    UH_REQUIRE(w && w_fwd && Cout > 0 && C0 > 0 && C1 >= 0, "uh_pack_w3x3_padded: bad arguments");
+    UH_REQUIRE(Coutp >= Cout && Cp0 >= C0 && Cp1 >= C1, "uh_pack_w3x3_padded: padded counts below the real ones");
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16, "uh_pack_w3x3_padded: bad dtype %d", dt);
+    int64_t total = (int64_t)Coutp * 9 * (Cp0 + Cp1);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == UH_BF16)
+        hipLaunchKernelGGL(pack_w3x3_padded_kernel<bf16_t>, grid, block, 0, st, w, sO, sI, sH, sW, Cout, C0, C1, Coutp, Cp0, Cp1,
+                           (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+    else
+        hipLaunchKernelGGL(pack_w3x3_padded_kernel<float>, grid, block, 0, st, w, sO, sI, sH, sW, Cout, C0, C1, Coutp, Cp0, Cp1,
+                           (float*)w_fwd, (float*)w_dgrad);
+    UH_CHECK_LAUNCH("uh_pack_w3x3_padded");
+    return UH_OK;
+}
+
 // All 3x3 filters of a model in ONE launch (the per-layer form costs ~10 us of launch + tail per layer, 18 layers per
 // step).  table[l] = {w pointer, sO, sI, sH, sW, Cout, Cin, first element of layer l in the flat outputs, first TILE of
 // layer l, 0}.  Workgroup = one 32(o) x 32(i) tile of one tap, transposed through LDS so that BOTH packed copies are

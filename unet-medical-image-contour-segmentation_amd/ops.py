@@ -575,43 +575,51 @@ class ConvBnReluNarrowFn(Function):
         dev = x0.device
         need_dx = (ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1])
         cdt = conv_dt(x0, Cp0, Cp1, Cop, any(need_dx) and training)
-        with torch.no_grad():
-            w32 = weight if weight.dtype == torch.float32 else weight.float()
-            wp = torch.zeros(Cop, Cinp, 3, 3, dtype=torch.float32, device=dev)
-            wp[:Cout, :c0_true] = w32[:, :c0_true]
-            if C1m:
-                wp[:Cout, Cp0:Cp0 + C1m] = w32[:, c0_true:]
-            gp = torch.ones(Cop, dtype=torch.float32, device=dev)
-            gp[:Cout] = gamma
-            bp = torch.zeros(Cop, dtype=torch.float32, device=dev)
-            bp[:Cout] = beta
-            rm = rv = None
-            if running_mean is not None:
-                rm = torch.zeros(Cop, dtype=torch.float32, device=dev)
-                rm[:Cout] = running_mean
-                rv = torch.ones(Cop, dtype=torch.float32, device=dev)
-                rv[:Cout] = running_var
         single = x1 is None
-        wf, wd0 = pack_w3x3(wp, x0.dtype, training and need_dx[0] and single, cdt)
-        wd1 = None
-        if training and not single:
-            # backward-data runs once per source (its own narrow dx): one flipped / transposed pack per channel block
-            wd0 = pack_w3x3(wp[:, :Cp0], x0.dtype, True, cdt)[1] if need_dx[0] else None
-            wd1 = pack_w3x3(wp[:, Cp0:], x0.dtype, True, cdt)[1] if need_dx[1] else None
-        coef = torch.empty(4 * Cop, dtype=torch.float32, device=dev)
-        scale, shift, mean, rstd = coef[:Cop], coef[Cop:2 * Cop], coef[2 * Cop:3 * Cop], coef[3 * Cop:]
+        want_wd = (training and need_dx[0], training and need_dx[1])
+        w32 = weight if weight.dtype == torch.float32 else weight.float()
+        wd0 = wd1 = None
+        if cdt == UH_F32X3:
+            # bf16x3 packs are [hi | lo] pairs, so the per-source backward-data filters cannot be row blocks of one pack:
+            # pad with torch, pack per source
+            with torch.no_grad():
+                wp = torch.zeros(Cop, Cinp, 3, 3, dtype=torch.float32, device=dev)
+                wp[:Cout, :c0_true] = w32[:, :c0_true]
+                if C1m:
+                    wp[:Cout, Cp0:Cp0 + C1m] = w32[:, c0_true:]
+            wf, wd0 = pack_w3x3(wp, x0.dtype, want_wd[0] and single, cdt)
+            if training and not single:
+                wd0 = pack_w3x3(wp[:, :Cp0], x0.dtype, True, cdt)[1] if want_wd[0] else None
+                wd1 = pack_w3x3(wp[:, Cp0:], x0.dtype, True, cdt)[1] if want_wd[1] else None
+        else:
+            # one launch: zero-padded forward pack + backward-data pack whose row blocks are the per-source filters
+            wf = torch.empty(Cop * 9 * Cinp, dtype=x0.dtype, device=dev)
+            wd = torch.empty(Cop * 9 * Cinp, dtype=x0.dtype, device=dev) if any(want_wd) else None
+            sO, sI, sH, sW = w32.stride()
+            LIB.call("uh_pack_w3x3_padded", w32.data_ptr(), sO, sI, sH, sW, Cout, c0_true, C1m, Cop, Cp0, Cp1, wf.data_ptr(),
+                     _p(wd), cdt, _stream())
+            if wd is not None:
+                wd0 = wd[:Cp0 * 9 * Cop] if want_wd[0] else None
+                wd1 = wd[Cp0 * 9 * Cop:] if want_wd[1] else None
+        g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
+        b32 = beta if beta.dtype == torch.float32 else beta.float()
         n = B * H * W
         ld0, ld1 = pixel_ld(x0), 0 if x1 is None else pixel_ld(x1)
         flops = 2.0 * n * Cop * 9 * Cinp
         if not training:
-            LIB.call("uh_bn_eval_coeffs", gp.data_ptr(), bp.data_ptr(), rm.data_ptr(), rv.data_ptr(), float(eps), Cop,
-                     scale.data_ptr(), shift.data_ptr(), _stream())
+            # scale / shift are read in 16-byte pieces for every padded channel group: Cop entries, the first Cout real
+            coef = torch.empty(2 * Cop, dtype=torch.float32, device=dev)
+            scale, shift = coef[:Cop], coef[Cop:]
+            LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                     float(eps), Cout, scale.data_ptr(), shift.data_ptr(), _stream())
             z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
             with _Timed("conv3x3_fwd_narrow", flops):
                 LIB.call("uh_conv3x3_fwd_narrow", x0.data_ptr(), Cp0, C0m, ld0, _p(x1), Cp1, C1m, ld1, wf.data_ptr(),
                          z.data_ptr(), Cout, Cop, Cout, None, scale.data_ptr(), shift.data_ptr(), B, H, W, cdt, _stream())
             ctx.training = False
             return z
+        coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
         y = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
         nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cinp, Cop, cdt)
         stats = torch.empty(nslab * (2 * Cop + 2), dtype=torch.float32, device=dev)
@@ -622,22 +630,19 @@ class ConvBnReluNarrowFn(Function):
         fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
         nbt_ptr = nbt.data_ptr() if fused_nbt else None
         n_total = n
+        # statistics rows are Cop channels wide (the conv is computed for the padded layer); only the Cout real ones count
         if SYNC_BN is None:
-            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cop, n, gp.data_ptr(), bp.data_ptr(), _p(rm), _p(rv),
-                     nbt_ptr, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                     rstd.data_ptr(), None, _stream())
+            LIB.call("uh_bn_finalize_ld", stats.data_ptr(), nslab, Cop, Cout, n, g32.data_ptr(), b32.data_ptr(),
+                     _p(running_mean), _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(),
+                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, _stream())
         else:
-            m2 = torch.empty(Cop, dtype=torch.float32, device=dev)
-            LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cop, n, gp.data_ptr(), bp.data_ptr(), None, None, None,
-                     float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+            m2 = torch.empty(Cout, dtype=torch.float32, device=dev)
+            LIB.call("uh_bn_finalize_ld", stats.data_ptr(), nslab, Cop, Cout, n, g32.data_ptr(), b32.data_ptr(), None, None,
+                     None, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                      m2.data_ptr(), _stream())
-            n_total = _sync_bn_forward(coef, m2, n, Cop, gp, bp, rm, rv, nbt_ptr, momentum, eps)
+            n_total = _sync_bn_forward(coef, m2, n, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps)
         if nbt is not None and not fused_nbt:
             nbt.add_(1)
-        if rm is not None:
-            with torch.no_grad():
-                running_mean.copy_(rm[:Cout])
-                running_var.copy_(rv[:Cout])
         z = torch.empty_like(y)
         LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout, n, Cout,
                  _dt(y), _stream())
@@ -661,7 +666,7 @@ class ConvBnReluNarrowFn(Function):
         n = B * H * W
         dev = y.device
         dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
-        scale, shift, mean, rstd = coef[:Cop], coef[Cop:2 * Cop], coef[2 * Cop:3 * Cop], coef[3 * Cop:]
+        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
         dt = _dt(y)
         nblk = LIB.query("uh_bn_bwd_nblk", n, Cout)
         partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
