@@ -506,7 +506,12 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const int co_blk = slab * BN;
     const int co_w = co_blk + wave * (NBW * 16);
     const int Cin = C0 + C1;
-    const int nchunk = Cin / CK;
+    // K-chunks that hold at least one stored channel: chunks beyond a source's valid count (narrow tensors) would be all
+    // zeros, so they are neither fetched nor multiplied.  Ordinary tensors: nch0 + nch1 == Cin / CK, chunk_of(v) == v.
+    const int nch0 = (C0v + CK - 1) / CK, nch1 = (C1v + CK - 1) / CK;
+    const int nchunk = nch0 + nch1;
+    const int skip1 = C0 / CK - nch0;             // chunk index jump between the last valid chunk of x0 and the first of x1
+    auto chunk_of = [&](int v) -> int { return v < nch0 ? v : v + skip1; };
     const int ntile = B * tilesX * tilesY;
 
     // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q).
@@ -603,16 +608,17 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
             for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int c = 0; c < nchunk; ++c, bufi ^= 1) {
-            if (c + 1 < nchunk) {
-                dma_chunk(pix_cur, c + 1, bufi ^ 1);
+        for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
+            const int c = chunk_of(v);
+            if (v + 1 < nchunk) {
+                dma_chunk(pix_cur, chunk_of(v + 1), bufi ^ 1);
             } else if (next_tile < ntile) {
                 tile_pixels(next_tile, pix_cur);        // the current tile has no DMA left to issue
                 dma_chunk(pix_cur, 0, bufi ^ 1);
             }
             const unsigned char* buf = lds + bufi * HALO2_BYTES;
             const int64_t wcp = (int64_t)c * CK;
-            const int64_t wcp_next = (int64_t)((c + 1 < nchunk) ? (c + 1) : 0) * CK;   // wraps to chunk 0 of the next tile
+            const int64_t wcp_next = (int64_t)((v + 1 < nchunk) ? chunk_of(v + 1) : 0) * CK;   // wraps to chunk 0 of the next tile
 #pragma unroll 1
             for (int s = 0; s < 3; ++s) {
                 // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
