@@ -138,7 +138,8 @@ def test_sync_bn_data_parallel_equals_single_process():
         uerr = float(((fp - p0) - (ref_p - p0)).norm() / (ref_p - p0).norm())
         perr = float((fp - ref_p).abs().max())
         assert gerr < 1e-3, f"gradient rel L2 {gerr:.3e}"
-        assert uerr < 2e-2 and perr < 1.5e-4, f"update rel L2 {uerr:.3e}, max abs diff {perr:.3e}"
+        # (one RMSprop step at lr 1e-4 moves an element by up to lr / sqrt(1 - alpha) = 1e-3)
+        assert uerr < 2e-2 and perr < 5e-4, f"update rel L2 {uerr:.3e}, max abs diff {perr:.3e}"
         for k, v in ref_run.items():
             if k.endswith("running_mean"):      # a mean is known to a fraction of the data's spread, not of its own size
                 std = ref_run[k.replace("running_mean", "running_var")].sqrt()
