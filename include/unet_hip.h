@@ -261,6 +261,12 @@ int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double n_mean, co
  * out[0] = (sum of small-area and near-edge penalties) / B, out[1] = number of external contours.
  * PARITY UNPINNED (OpenCV is not available in this image). */
 int uh_cc_loss_host(const uint8_t* masks, int B, int H, int W, int edge_distance, int min_area, double* out);
+/* The same loss with the masks left on the device: hole filling + 8-connected components by union-find,
+ * contourArea as the integer sum over 2x2 pixel blocks that the border polygon encloses (full squares + corner halves),
+ * boundingRect by integer atomics; out = DEVICE double[2] {sum of penalties / B, number of external contours}. */
+size_t uh_cc_loss_ws_bytes(int B, int H, int W);
+int uh_cc_loss_device(const uint8_t* masks, int B, int H, int W, int edge_distance, int min_area, void* ws, size_t ws_bytes,
+                      double* out, uh_stream stream);
 
 /* ---- inference masks  (predict.py:27, evaluate.py:60-62,111) ------------------------------------
  * uh_argmax_classes: logits fp32 [npix][ncls] -> int64 index of the first maximum per pixel (torch.argmax(dim=1)).

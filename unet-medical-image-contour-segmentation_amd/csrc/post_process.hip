@@ -120,7 +120,136 @@ __global__ void pp_keep_kernel(const int* __restrict__ root, const int* __restri
     out[p] = (r >= 0 && area[r] >= min_area) ? 2 : 0;
 }
 
+// ---- connected_component_loss on the device (utils/connected_component_loss.py:20-59) -------------
+// cv2.findContours(RETR_EXTERNAL) returns the outer border of every 8-connected foreground component that is not nested
+// inside another one; what the loss uses of it:
+//   * cv2.contourArea = area of the polygon through the border pixels' centres.  That polygon bounds exactly the unit
+//     squares whose 4 corner pixels belong to the (hole-filled) component plus half a square for every 2x2 block with 3
+//     of them (8-connectivity cuts the corner diagonally; blocks with 2 or fewer contribute a line): twice the area is
+//     an INTEGER sum over 2x2 blocks -- no border following needed;
+//   * cv2.boundingRect = bounding box of the component's pixels.
+// "Not nested" + "outer border only" == label the HOLE-FILLED foreground: background components (4-connected) that do not
+// reach the image border are filled first, which also swallows any blob sitting inside such a hole.
+__global__ void cc_select_kernel(const unsigned char* __restrict__ mask, unsigned char* __restrict__ fg,
+                                 unsigned char* __restrict__ bg, long long n) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const unsigned char f = mask[p] != 0;
+    fg[p] = f;
+    bg[p] = !f;
+}
+__global__ void cc_clear_kernel(int* __restrict__ x0, int* __restrict__ y0, int* __restrict__ x1, int* __restrict__ y1,
+                                int* __restrict__ area2, long long n) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    x0[p] = 0x7fffffff; y0[p] = 0x7fffffff; x1[p] = -1; y1[p] = -1; area2[p] = 0;
+}
+// per component (indexed by its root pixel): bounding box and twice the contour area; integer atomics only
+__global__ void cc_stats_kernel(const unsigned char* __restrict__ sel, const int* __restrict__ L, int* __restrict__ root,
+                                int* __restrict__ x0, int* __restrict__ y0, int* __restrict__ x1, int* __restrict__ y1,
+                                int* __restrict__ area2, int H, int W, long long n) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    int r = -1;
+    if (sel[p]) {
+        r = pp_find(L, (int)p);
+        atomicMin(x0 + r, x); atomicMax(x1 + r, x);
+        atomicMin(y0 + r, y); atomicMax(y1 + r, y);
+    }
+    root[p] = r;
+    if (x + 1 < W && y + 1 < H) {                                  // the 2x2 block whose top-left pixel is p
+        const int a = sel[p] != 0, b = sel[p + 1] != 0, c = sel[p + W] != 0, d = sel[p + W + 1] != 0;
+        const int cnt = a + b + c + d;
+        if (cnt >= 3) {                                            // its foreground pixels are mutually 8-connected
+            const int q = a ? (int)p : (int)p + 1;                 // at most one corner is missing
+            const int rr = a ? r : pp_find(L, q);
+            atomicAdd(area2 + rr, cnt == 4 ? 2 : 1);
+        }
+    }
+}
+// one block: penalties of all components (connected_component_loss.py:35-56), summed in a fixed order in double
+__global__ __launch_bounds__(1024) void cc_penalty_kernel(const int* __restrict__ root, const int* __restrict__ x0,
+                                                          const int* __restrict__ y0, const int* __restrict__ x1,
+                                                          const int* __restrict__ y1, const int* __restrict__ area2, int B,
+                                                          int H, int W, int edge_distance, int min_area, long long n,
+                                                          double* __restrict__ out) {
+    __shared__ double red[2][1024];
+    double pen = 0.0, cnt = 0.0;
+    for (long long p = threadIdx.x; p < n; p += 1024) {
+        if (root[p] != (int)p) continue;                           // one thread per component: its root pixel
+        cnt += 1.0;
+        const double area = 0.5 * (double)area2[p];
+        if (area < (double)min_area) { pen += 1.0 - area / (double)min_area; continue; }      // :37-41
+        const int wc = x1[p] - x0[p] + 1, hc = y1[p] - y0[p] + 1;  // cv2.boundingRect
+        const int cx = x0[p] + wc / 2, cy = y0[p] + hc / 2;        // :45-46
+        int d = cx;
+        if (W - cx < d) d = W - cx;
+        if (cy < d) d = cy;
+        if (H - cy < d) d = H - cy;                                // :49-51
+        if (d < edge_distance) pen += 1.0 - (double)d / (double)edge_distance;                // :53-56
+    }
+    red[0][threadIdx.x] = pen;
+    red[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0] / (double)B; out[1] = red[1][0]; }
+}
+
 }  // namespace
+
+extern "C" size_t uh_cc_loss_ws_bytes(int B, int H, int W) {
+    const size_t n = (size_t)B * H * W;
+    return 8 * n * sizeof(int) + 3 * ((n + 15) & ~(size_t)15) + 256;
+}
+
+// masks: DEVICE uint8 [B][H][W] (non-zero = foreground = p > 0.5, connected_component_loss.py:25); out: DEVICE double[2] =
+// {sum of penalties / B (the caller multiplies by penalty_weight, :59), number of external contours}.  Same values as
+// uh_cc_loss_host (which follows the borders on the host) without the device -> host copy of the masks.
+extern "C" int uh_cc_loss_device(const uint8_t* masks, int B, int H, int W, int edge_distance, int min_area, void* ws,
+                                 size_t ws_bytes, double* out, uh_stream stream) {
+    UH_REQUIRE(masks && out && ws && B > 0 && H > 0 && W > 0 && edge_distance > 0 && min_area > 0, "uh_cc_loss_device: bad args");
+    UH_REQUIRE((long long)B * H * W < (1ll << 31), "uh_cc_loss_device: pixel count overflows int32");
+    const size_t need = uh_cc_loss_ws_bytes(B, H, W);
+    if (ws_bytes < need) {
+        uh_set_error("uh_cc_loss_device: workspace %zu < %zu bytes", ws_bytes, need);
+        return UH_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * H * W;
+    const size_t nb = ((size_t)n + 15) & ~(size_t)15;
+    int* L = (int*)ws;
+    int* root = L + n;
+    int* aux = root + n;
+    int* bx0 = aux + n;
+    int* by0 = bx0 + n;
+    int* bx1 = by0 + n;
+    int* by1 = bx1 + n;
+    int* area2 = by1 + n;
+    unsigned char* fg = (unsigned char*)(area2 + n);
+    unsigned char* bg = fg + nb;
+    unsigned char* filled = bg + nb;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(cc_select_kernel, grid, blk, 0, st, masks, fg, bg, n);
+    // holes (and whatever sits in them) become foreground: only outermost outer borders count
+    hipLaunchKernelGGL(pp_init_kernel, grid, blk, 0, st, (const unsigned char*)bg, L, aux, n);
+    hipLaunchKernelGGL(pp_union_kernel<false>, grid, blk, 0, st, (const unsigned char*)bg, L, H, W, n);
+    hipLaunchKernelGGL(pp_flatten_kernel<0>, grid, blk, 0, st, (const int*)L, root, aux, H, W, n);
+    hipLaunchKernelGGL(pp_fill_kernel, grid, blk, 0, st, (const unsigned char*)fg, (const int*)root, (const int*)aux, filled, n);
+    // 8-connected components of the filled foreground, their bounding boxes and contour areas
+    hipLaunchKernelGGL(pp_init_kernel, grid, blk, 0, st, (const unsigned char*)filled, L, aux, n);
+    hipLaunchKernelGGL(pp_union_kernel<true>, grid, blk, 0, st, (const unsigned char*)filled, L, H, W, n);
+    hipLaunchKernelGGL(cc_clear_kernel, grid, blk, 0, st, bx0, by0, bx1, by1, area2, n);
+    hipLaunchKernelGGL(cc_stats_kernel, grid, blk, 0, st, (const unsigned char*)filled, (const int*)L, root, bx0, by0, bx1, by1, area2,
+                       H, W, n);
+    hipLaunchKernelGGL(cc_penalty_kernel, dim3(1), dim3(1024), 0, st, (const int*)root, (const int*)bx0, (const int*)by0,
+                       (const int*)bx1, (const int*)by1, (const int*)area2, B, H, W, edge_distance, min_area, n, out);
+    UH_CHECK_LAUNCH("uh_cc_loss_device");
+    return UH_OK;
+}
 
 extern "C" size_t uh_postprocess_ws_bytes(int B, int H, int W) {
     const size_t n = (size_t)B * H * W;
