@@ -261,7 +261,7 @@ class GraphedTrainStepper(TrainStepper):
         if self.world != 1:
             raise RuntimeError("GraphedTrainStepper is single-process; use TrainStepper with torch.distributed")
         if self.cc_loss:
-            raise RuntimeError("connected_component_loss copies masks to the host every step: not capturable")
+            raise RuntimeError("connected_component_loss returns a Python float (a device read-back every step): not capturable")
         self._warmup = max(1, warmup)
         self._graph = None
         self._key = None
