@@ -175,8 +175,9 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
                          boundary_weight=boundary_weight)
     if cc_loss and model.n_classes == 1:
         # the block train.py:124-132 keeps commented out (BASELINE config 5 turns it on): a Python float, no gradient.
-        # sigmoid(x) > 0.5 <=> x > 0, so the 0/1 threshold mask stands in for the probabilities; like the reference this
-        # copies the batch's binary masks to the host and waits for them.
+        # sigmoid(x) > 0.5 <=> x > 0, so the 0/1 threshold mask stands in for the probabilities.  The masks stay on the
+        # device (uh_cc_loss_device); only the resulting scalar is read back, which waits for the forward like the
+        # reference's .cpu() does.
         from .utils.connected_component_loss import connected_component_loss
         cc = connected_component_loss(ops.threshold_mask(masks_pred.detach().squeeze(1)), edge_distance=50, min_area=1000,
                                       penalty_weight=0.1)
