@@ -181,3 +181,51 @@ def test_checkpoint_round_trip_on_gpu(tmp_path):
     a.eval(); b.eval()
     with torch.no_grad():
         assert torch.equal(a(x), b(x))
+
+
+def test_eval_batchnorm_coefficients_are_cached_and_invalidated():
+    """The inference path folds BatchNorm(eval) to scale/shift once per BatchNorm and reuses it; anything that changes a
+    parameter or a running statistic (a train-mode forward writes them through raw pointers; load_state_dict; in-place
+    edits) must drop the cache."""
+    import unet_amd
+    from unet_amd._lib import LIB
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    x = torch.rand(2, 1, 64, 64, device=dev)
+    calls = []
+    real = LIB.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    LIB.call = spy
+    try:
+        m.eval()
+        with torch.no_grad():
+            y0 = m(x).clone()
+            n0 = calls.count("uh_bn_eval_coeffs")
+            y1 = m(x).clone()
+            assert calls.count("uh_bn_eval_coeffs") == n0, "coefficients were recomputed"
+            assert n0 == 18 and torch.equal(y0, y1)
+        m.train()
+        m(x)                                   # rewrites the running statistics
+        m.eval()
+        with torch.no_grad():
+            y2 = m(x).clone()
+        assert calls.count("uh_bn_eval_coeffs") == 2 * n0
+        assert not torch.equal(y0, y2)
+        with torch.no_grad():
+            m.inc.double_conv[1].running_var.mul_(4.0)          # an in-place edit bumps the version
+            y3 = m(x).clone()
+        assert calls.count("uh_bn_eval_coeffs") == 2 * n0 + 1 and not torch.equal(y2, y3)
+        # the reference semantics, recomputed from scratch by stock PyTorch modules
+        ref = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+        ref.load_state_dict(m.state_dict())
+        ref.eval()
+        with torch.no_grad():
+            y4 = ref(x)
+        assert torch.allclose(y3, y4, rtol=1e-5, atol=1e-6)
+    finally:
+        LIB.call = real

@@ -199,6 +199,35 @@ def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor
     return wf
 
 
+# Bumped whenever a training-mode forward rewrites BatchNorm running statistics through raw pointers (no torch version
+# bump): the inference path caches the eval-mode scale / shift per BatchNorm until then.
+BN_STATS_EPOCH = 0
+
+
+def bn_eval_coeffs_cached(gamma, beta, running_mean, running_var, eps: float, C: int, Cp: int):
+    """-> (scale, shift) fp32 views of Cp entries each, the first C real: eval-mode BatchNorm (evaluate.py:30, predict.py:17)
+    folded to one multiply-add, cached on the gamma parameter until a parameter or a running statistic changes."""
+    try:
+        key = (gamma.data_ptr(), gamma._version, beta._version, running_mean._version, running_var._version, WEIGHT_EPOCH,
+               BN_STATS_EPOCH, float(eps), C, Cp)
+    except RuntimeError:                      # inference tensors carry no version counter
+        key = None
+    hit = getattr(gamma, "_uh_bn_eval", None) if key is not None else None
+    if hit is not None and hit[0] == key:
+        return hit[1][:Cp], hit[1][Cp:]
+    g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
+    b32 = beta if beta.dtype == torch.float32 else beta.float()
+    coef = torch.empty(2 * Cp, dtype=torch.float32, device=gamma.device)
+    LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps),
+             C, coef.data_ptr(), coef[Cp:].data_ptr(), _stream())
+    if key is not None:
+        try:
+            gamma._uh_bn_eval = (key, coef)
+        except AttributeError:
+            pass
+    return coef[:Cp], coef[Cp:]
+
+
 class ConvWeightPack:
     """Packed (KRSC forward + flipped/transposed backward-data) copies of ALL 3x3 filters of a model, refreshed by one
     kernel launch per train step (TrainStepper) instead of one launch per layer inside the forward."""
@@ -412,6 +441,8 @@ class ConvBnReluFn(Function):
         g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
         b32 = beta if beta.dtype == torch.float32 else beta.float()
         if training:
+            global BN_STATS_EPOCH
+            BN_STATS_EPOCH += 1                   # running statistics are about to change under torch's feet
             y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt)
             nbt = num_batches_tracked
             fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
@@ -433,8 +464,7 @@ class ConvBnReluFn(Function):
         else:
             # inference (model.eval(): evaluate.py:30, predict.py:17): running statistics -> per-channel scale/shift,
             # applied with the ReLU inside the conv epilogue; nothing is kept for a backward pass
-            LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(),
-                     running_var.data_ptr(), float(eps), Cout, scale.data_ptr(), shift.data_ptr(), _stream())
+            scale, shift = bn_eval_coeffs_cached(gamma, beta, running_mean, running_var, eps, Cout, Cout)
             z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
             LIB.call("uh_conv3x3_fwd_affine_relu", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
                      pixel_ld(x1) if x1 is not None else 0, wf.data_ptr(), z.data_ptr(), Cout, Cout, scale.data_ptr(),
@@ -608,10 +638,7 @@ class ConvBnReluNarrowFn(Function):
         flops = 2.0 * n * Cop * 9 * Cinp
         if not training:
             # scale / shift are read in 16-byte pieces for every padded channel group: Cop entries, the first Cout real
-            coef = torch.empty(2 * Cop, dtype=torch.float32, device=dev)
-            scale, shift = coef[:Cop], coef[Cop:]
-            LIB.call("uh_bn_eval_coeffs", g32.data_ptr(), b32.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
-                     float(eps), Cout, scale.data_ptr(), shift.data_ptr(), _stream())
+            scale, shift = bn_eval_coeffs_cached(gamma, beta, running_mean, running_var, eps, Cout, Cop)
             z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
             with _Timed("conv3x3_fwd_narrow", flops):
                 LIB.call("uh_conv3x3_fwd_narrow", x0.data_ptr(), Cp0, C0m, ld0, _p(x1), Cp1, C1m, ld1, wf.data_ptr(),
@@ -620,6 +647,8 @@ class ConvBnReluNarrowFn(Function):
             return z
         coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
         scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
+        global BN_STATS_EPOCH
+        BN_STATS_EPOCH += 1                       # running statistics are about to change under torch's feet
         y = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
         nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cinp, Cop, cdt)
         stats = torch.empty(nslab * (2 * Cop + 2), dtype=torch.float32, device=dev)
