@@ -208,8 +208,8 @@ def bn_eval_coeffs_cached(gamma, beta, running_mean, running_var, eps: float, C:
     """-> (scale, shift) fp32 views of Cp entries each, the first C real: eval-mode BatchNorm (evaluate.py:30, predict.py:17)
     folded to one multiply-add, cached on the gamma parameter until a parameter or a running statistic changes."""
     try:
-        key = (gamma.data_ptr(), gamma._version, beta._version, running_mean._version, running_var._version, WEIGHT_EPOCH,
-               BN_STATS_EPOCH, float(eps), C, Cp)
+        key = (gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), gamma._version,
+               beta._version, running_mean._version, running_var._version, WEIGHT_EPOCH, BN_STATS_EPOCH, float(eps), C, Cp)
     except RuntimeError:                      # inference tensors carry no version counter
         key = None
     hit = getattr(gamma, "_uh_bn_eval", None) if key is not None else None
