@@ -167,6 +167,40 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
     }
 }
 
+// Same arithmetic, cheaper indexing: one output row (b, oy) per blockIdx.x, so the row decode is scalar and the column /
+// channel-group split is a 32-bit shift (or one 32-bit division).  The grid-stride form above spends ~200 VALU
+// instructions on 64-bit div / mod per 16 bytes written and runs at 2.9 TB/s: it is instruction-bound, not HBM-bound.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                                  int h, int w, int C, int Ho, int Wo, int pt, int pl,
+                                                                  float sy, float sx, int gshift) {
+    const int G = C / V;
+    const int row = blockIdx.x;                         // b * Ho + oy
+    const int b = row / Ho, oy = row - b * Ho;
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    if (t >= Wo * G) return;
+    const int ox = gshift >= 0 ? (t >> gshift) : (t / G);
+    const int c = (t - ox * G) * V;
+    float o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = 0.f;
+    const int uy = oy - pt, ux = ox - pl;
+    if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+        const UpCoord cy = up_coord(uy, sy, h), cx = up_coord(ux, sx, w);
+        const T* r0 = x + ((int64_t)(b * h + cy.i0) * w) * ldx + c;
+        const T* r1 = x + ((int64_t)(b * h + cy.i1) * w) * ldx + c;
+        float v00[V], v01[V], v10[V], v11[V];
+        uh_load<T, V>(r0 + (int64_t)cx.i0 * ldx, v00);
+        uh_load<T, V>(r0 + (int64_t)cx.i1 * ldx, v01);
+        uh_load<T, V>(r1 + (int64_t)cx.i0 * ldx, v10);
+        uh_load<T, V>(r1 + (int64_t)cx.i1 * ldx, v11);
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            o[i] = cy.l0 * (cx.l0 * v00[i] + cx.l1 * v01[i]) + cy.l1 * (cx.l0 * v10[i] + cx.l1 * v11[i]);
+    }
+    uh_store<T, V>(y + ((int64_t)row * Wo + ox) * ldy + c, o);
+}
+
 // gather form of the transpose: every input pixel collects from the output pixels that read it
 __device__ __forceinline__ void up_range(int i, float scale, int in, int& lo, int& hi) {
     const int out = 2 * in;
@@ -327,7 +361,16 @@ extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B
     float sy = up_scale(h), sx = up_scale(w);
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
+        if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C) && (int64_t)Wo * (C / VEC) < (1 << 23) &&
+            (int64_t)B * Ho < (1ll << 31)) {
+            const int G = C / VEC;
+            int gshift = -1;
+            for (int k = 0; k < 24; ++k)
+                if ((1 << k) == G) gshift = k;
+            const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
+            hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * Ho), gy), dim3(256), 0, st, (const T*)x,
+                               ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift);
+        } else if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
             hipLaunchKernelGGL((upsample2x_fwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
                                (const T*)x, ldx, (T*)y, ldy, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
         else
