@@ -167,38 +167,76 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
     }
 }
 
-// Same arithmetic, cheaper indexing: one output row (b, oy) per blockIdx.x, so the row decode is scalar and the column /
-// channel-group split is a 32-bit shift (or one 32-bit division).  The grid-stride form above spends ~200 VALU
-// instructions on 64-bit div / mod per 16 bytes written and runs at 2.9 TB/s: it is instruction-bound, not HBM-bound.
+// Same arithmetic, far fewer instructions per byte written (the grid-stride form above spends ~200 VALU instructions --
+// 64-bit div / mod, coordinates, four 8-value unpacks -- on every 16 bytes and runs at 2.9 TB/s: instruction-bound).
+// Here a workgroup row (blockIdx.x) is FOUR consecutive output rows of one image: the row decode and the vertical
+// coordinates are scalar, a thread = (output column, 16-byte channel group) loads the input rows those four output
+// rows touch (x 2 columns; at most 4), interpolates them horizontally once, and blends each output row from two of the three
+// horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                                   int h, int w, int C, int Ho, int Wo, int pt, int pl,
                                                                   float sy, float sx, int gshift) {
+    constexpr int R = 4;
     const int G = C / V;
-    const int row = blockIdx.x;                         // b * Ho + oy
-    const int b = row / Ho, oy = row - b * Ho;
+    const int groups = (Ho + R - 1) / R;
+    const int b = blockIdx.x / groups, oy0 = (blockIdx.x - b * groups) * R;
     const int t = blockIdx.y * 256 + threadIdx.x;
     if (t >= Wo * G) return;
     const int ox = gshift >= 0 ? (t >> gshift) : (t / G);
     const int c = (t - ox * G) * V;
-    float o[V];
+    const int ux = ox - pl;
+    const bool col_in = ux >= 0 && ux < 2 * w;
+    // vertical coordinates of the R output rows (scalar): rows outside the up-sampled image are zero padding (F.pad)
+    UpCoord cy[R];
+    bool row_in[R];
+    int base = h - 1;
 #pragma unroll
-    for (int i = 0; i < V; ++i) o[i] = 0.f;
-    const int uy = oy - pt, ux = ox - pl;
-    if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
-        const UpCoord cy = up_coord(uy, sy, h), cx = up_coord(ux, sx, w);
-        const T* r0 = x + ((int64_t)(b * h + cy.i0) * w) * ldx + c;
-        const T* r1 = x + ((int64_t)(b * h + cy.i1) * w) * ldx + c;
-        float v00[V], v01[V], v10[V], v11[V];
-        uh_load<T, V>(r0 + (int64_t)cx.i0 * ldx, v00);
-        uh_load<T, V>(r0 + (int64_t)cx.i1 * ldx, v01);
-        uh_load<T, V>(r1 + (int64_t)cx.i0 * ldx, v10);
-        uh_load<T, V>(r1 + (int64_t)cx.i1 * ldx, v11);
-#pragma unroll
-        for (int i = 0; i < V; ++i)
-            o[i] = cy.l0 * (cx.l0 * v00[i] + cx.l1 * v01[i]) + cy.l1 * (cx.l0 * v10[i] + cx.l1 * v11[i]);
+    for (int r = 0; r < R; ++r) {
+        const int uy = oy0 + r - pt;
+        row_in[r] = (oy0 + r < Ho) && uy >= 0 && uy < 2 * h;
+        cy[r] = up_coord(row_in[r] ? uy : 0, sy, h);
+        if (row_in[r] && cy[r].i0 < base) base = cy[r].i0;
     }
-    uh_store<T, V>(y + ((int64_t)row * Wo + ox) * ldy + c, o);
+    // four output rows advance the source row by < 1.5, so they touch input rows base .. base+3 at most
+    constexpr int NR = 4;
+    float hr[NR][V];                                   // horizontally interpolated input rows base .. base+3
+    if (col_in) {
+        const UpCoord cx = up_coord(ux, sx, w);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int iy = min(base + j, h - 1);
+            const T* rp = x + ((int64_t)(b * h + iy) * w) * ldx + c;
+            float v0[V], v1[V];
+            uh_load<T, V>(rp + (int64_t)cx.i0 * ldx, v0);
+            uh_load<T, V>(rp + (int64_t)cx.i1 * ldx, v1);
+#pragma unroll
+            for (int i = 0; i < V; ++i) hr[j][i] = cx.l0 * v0[i] + cx.l1 * v1[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (oy0 + r >= Ho) break;
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = 0.f;
+        if (row_in[r] && col_in) {
+            const int a = cy[r].i0 - base, bb = cy[r].i1 - base;      // in 0..3, uniform over the workgroup: scalar branches
+            const float l0 = cy[r].l0, l1 = cy[r].l1;
+            float ra[V], rb[V];
+            auto pick = [&](int k, float (&dst)[V]) {
+                if (k == 0) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[0][i]; }
+                else if (k == 1) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[1][i]; }
+                else if (k == 2) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[2][i]; }
+                else { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[3][i]; }
+            };
+            pick(a, ra);
+            pick(bb, rb);
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = l0 * ra[i] + l1 * rb[i];
+        }
+        uh_store<T, V>(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c, o);
+    }
 }
 
 // gather form of the transpose: every input pixel collects from the output pixels that read it
@@ -307,13 +345,40 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __re
             const int ux = uxb + k, ox = ux + pl;
             wxs[k] = (ux >= 0 && ux < 2 * w && ox >= 0 && ox < Wo) ? up_weight(ux, sx, w, ix) : 0.f;
         }
+        int kval = 2;                       // a candidate column with a non-zero weight (2 and 3 always straddle ix)
+#pragma unroll
+        for (int k = NC - 1; k >= 0; --k)
+            if (wxs[k] != 0.f) kval = k;
         const int uy_lo = max(0, 2 * iy0 - 2), uy_hi = min(2 * h - 1, 2 * (iy1 - 1) + 3);
         float a0[V], a1[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
         int cur = up_coord(uy_lo, sy, h).i0;
         T* dxp = dx + ((int64_t)b * h * w + ix) * lddx + c;
-        for (int uy = uy_lo; uy <= uy_hi; ++uy) {
+        // column pass of one output row: tt = sum_k wxs[k] * dy[oy][uxb + pl + k]  (zero for a padding row).  Branch-free:
+        // every load goes to a valid address (row and column clamped to ones this thread does use) and a value that
+        // must not count is replaced by 0 AFTER the load -- so the loads of two rows (<= 12) are all in flight before the
+        // first one is consumed, and a NaN in a pixel this input does not depend on cannot leak in through a zero weight.
+        auto row_sum = [&](int uy, float (&tt)[V]) {
+            const int oy = uy + pt;
+            const bool live = uy <= uy_hi && oy >= 0 && oy < Ho;
+            const int oyc = min(max(oy, 0), Ho - 1);
+            const T* row = dy + ((int64_t)(b * Ho + oyc) * Wo + uxb + pl) * lddy + c;
+            float g[NC][V];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) uh_load<T, V>(row + (int64_t)(wxs[k] != 0.f ? k : kval) * lddy, g[k]);
+#pragma unroll
+            for (int i = 0; i < V; ++i) tt[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const bool use = live && wxs[k] != 0.f;
+#pragma unroll
+                for (int i = 0; i < V; ++i) tt[i] = use ? fmaf(wxs[k], g[k][i], tt[i]) : tt[i];
+            }
+        };
+        // row pass: fold the column sums of output row uy into the two running input-row accumulators
+        auto row_acc = [&](int uy, const float (&tt)[V]) {
+            if (uy > uy_hi) return;
             const UpCoord cy = up_coord(uy, sy, h);
             if (cy.i0 > cur) {              // row `cur` is complete (i0 advances by at most one per output row)
                 if (cur >= iy0 && cur < iy1) uh_store<T, V>(dxp + (int64_t)cur * w * lddx, a0);
@@ -322,20 +387,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __re
                 cur = cy.i0;
             }
             const int oy = uy + pt;
-            if (oy < 0 || oy >= Ho) continue;
-            const T* row = dy + ((int64_t)(b * Ho + oy) * Wo + uxb + pl) * lddy + c;
-            float tt[V];
-#pragma unroll
-            for (int i = 0; i < V; ++i) tt[i] = 0.f;
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                if (wxs[k] != 0.f) {
-                    float g[V];
-                    uh_load<T, V>(row + (int64_t)k * lddy, g);
-#pragma unroll
-                    for (int i = 0; i < V; ++i) tt[i] = fmaf(wxs[k], g[i], tt[i]);
-                }
-            }
+            if (oy < 0 || oy >= Ho) return;
             if (cy.i1 == cy.i0) {
                 const float wsum = cy.l0 + cy.l1;
 #pragma unroll
@@ -344,6 +396,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __re
 #pragma unroll
                 for (int i = 0; i < V; ++i) { a0[i] = fmaf(cy.l0, tt[i], a0[i]); a1[i] = fmaf(cy.l1, tt[i], a1[i]); }
             }
+        };
+        // two output rows per trip: the (up to 12) loads of both rows are independent of the accumulators
+        for (int uy = uy_lo; uy <= uy_hi; uy += 2) {
+            float t0[V], t1[V];
+            row_sum(uy, t0);
+            row_sum(uy + 1, t1);
+            row_acc(uy, t0);
+            row_acc(uy + 1, t1);
         }
         if (cur >= iy0 && cur < iy1) uh_store<T, V>(dxp + (int64_t)cur * w * lddx, a0);
         if (cur + 1 >= iy0 && cur + 1 < iy1) uh_store<T, V>(dxp + (int64_t)(cur + 1) * w * lddx, a1);
@@ -368,7 +428,7 @@ extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B
             for (int k = 0; k < 24; ++k)
                 if ((1 << k) == G) gshift = k;
             const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
-            hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * Ho), gy), dim3(256), 0, st, (const T*)x,
+            hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * ((Ho + 3) / 4)), gy), dim3(256), 0, st, (const T*)x,
                                ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift);
         } else if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
             hipLaunchKernelGGL((upsample2x_fwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
