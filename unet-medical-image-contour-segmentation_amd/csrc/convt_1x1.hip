@@ -327,6 +327,62 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// The common shape (Cin == LPP * V: one 16-byte piece per lane and pixel; n_classes <= 4 as a template constant): this
+// lane's filter taps live in registers (no LDS, no barrier), U pixels per trip, the class loop fully unrolled.  The generic
+// kernel above keeps the class count dynamic and re-reads its taps from LDS inside the pixel loop -- 2 477 instructions of
+// branches and waits that held it at 4 TB/s.
+template <typename T, int V, int NC, int LPP>
+__global__ __launch_bounds__(256) void conv1x1_fwd_nc_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ logits,
+                                                             int64_t npix) {
+    constexpr int Cin = LPP * V;
+    constexpr int PPB = 256 / LPP;
+    constexpr int U = 4;
+    const int sub = threadIdx.x % LPP;
+    float wr[NC][V], bs[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        bs[k] = bias[k];
+#pragma unroll
+        for (int i = 0; i < V; ++i) wr[k][i] = w[k * Cin + sub * V + i];
+    }
+    for (int64_t p0 = (int64_t)blockIdx.x * (U * PPB) + threadIdx.x / LPP; p0 < npix; p0 += (int64_t)gridDim.x * (U * PPB)) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + (int64_t)u * PPB;
+            const int64_t pc = p < npix ? p : npix - 1;              // clamped: the tail lanes load a valid pixel, store nothing
+            uh_load<T, V>(x + pc * ldx + sub * V, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + (int64_t)u * PPB;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < V; ++i) a = fmaf(v[u][i], wr[k][i], a);
+#pragma unroll
+                for (int o = LPP >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (sub == 0 && p < npix) logits[p * NC + k] = a + bs[k];
+            }
+        }
+    }
+}
+
+template <typename T, int V, int LPP>
+static void c11_fwd_nc_launch(int ncls, const T* x, int ldx, const float* w, const float* bias, float* logits, int64_t npix,
+                              hipStream_t st) {
+    const int ppb4 = 4 * (256 / LPP);                      // pixels per workgroup trip
+    const unsigned grid = ct_grid((npix + ppb4 - 1) / ppb4 * 256);
+    switch (ncls) {
+        case 1: hipLaunchKernelGGL((conv1x1_fwd_nc_kernel<T, V, 1, LPP>), dim3(grid), dim3(256), 0, st, x, ldx, w, bias, logits, npix); break;
+        case 2: hipLaunchKernelGGL((conv1x1_fwd_nc_kernel<T, V, 2, LPP>), dim3(grid), dim3(256), 0, st, x, ldx, w, bias, logits, npix); break;
+        case 3: hipLaunchKernelGGL((conv1x1_fwd_nc_kernel<T, V, 3, LPP>), dim3(grid), dim3(256), 0, st, x, ldx, w, bias, logits, npix); break;
+        default: hipLaunchKernelGGL((conv1x1_fwd_nc_kernel<T, V, 4, LPP>), dim3(grid), dim3(256), 0, st, x, ldx, w, bias, logits, npix); break;
+    }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w,
                                                             T* __restrict__ dx, int lddx, int64_t npix, int Cin, int ncls) {
@@ -373,19 +429,21 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
         if (act)
             for (int64_t p = (int64_t)blockIdx.x * (U * PL) + pl; p < npix; p += (int64_t)gridDim.x * (U * PL)) {
                 float xv[U][V], g[U][NC];
+                // branch-free: the tail loads a clamped (valid) pixel and its gradient is replaced by 0 -- a branch
+                // around each load made the compiler wait for it before issuing the next one
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t q = p + (int64_t)u * PL;
-                    if (q < npix) {
-                        uh_load<T, V>(x + q * ldx + c, xv[u]);
+                    const int64_t qc = q < npix ? q : npix - 1;
+                    uh_load<T, V>(x + qc * ldx + c, xv[u]);
 #pragma unroll
-                        for (int k = 0; k < NC; ++k) g[u][k] = dl[q * NC + k];
-                    } else {
+                    for (int k = 0; k < NC; ++k) g[u][k] = dl[qc * NC + k];
+                }
 #pragma unroll
-                        for (int i = 0; i < V; ++i) xv[u][i] = 0.f;
+                for (int u = 0; u < U; ++u) {
+                    const bool in = p + (int64_t)u * PL < npix;
 #pragma unroll
-                        for (int k = 0; k < NC; ++k) g[u][k] = 0.f;
-                    }
+                    for (int k = 0; k < NC; ++k) g[u][k] = in ? g[u][k] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -453,7 +511,10 @@ extern "C" int uh_conv1x1_fwd(const void* x, int ldx, const float* w, const floa
     size_t sm = (size_t)ncls * Cin * sizeof(float);
     UH_DISPATCH_DT(dt, T, {
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (uh_vec_ok<T>(x, ldx, Cin)) {
+        if (uh_vec_ok<T>(x, ldx, Cin) && (Cin == 8 * VEC || Cin == 16 * VEC) && ncls <= 4) {      // the UNet head: 64 channels
+            if (Cin == 8 * VEC) c11_fwd_nc_launch<T, VEC, 8>(ncls, (const T*)x, ldx, w, bias, logits, npix, st);
+            else c11_fwd_nc_launch<T, VEC, 16>(ncls, (const T*)x, ldx, w, bias, logits, npix, st);
+        } else if (uh_vec_ok<T>(x, ldx, Cin)) {
             int G = Cin / VEC, LPP = 1;
             while (LPP * 2 <= G && LPP < 64) LPP *= 2;   // power of two lanes per pixel
             int ppb = 256 / LPP;
