@@ -1951,6 +1951,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict
         const int b = t / tilesY;
         const int y0 = tyt * TILE, x0p = txt * TILE;
         const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
+        // this thread's eight 16-byte pieces of dy are requested FIRST, branch-free (clamped to a pixel of the tile, masked
+        // below), so they travel while the image tile is staged and the two barriers pass: a load inside each
+        // `if (pixel in tile)` was waited for before the next one was issued -- eight exposed HBM round trips per tile
+        static_assert(sizeof(T) == 2, "stem_v3 is the bf16 kernel");
+        constexpr int DEPTH = 4;            // pieces in flight (a rolling window: 16 VGPRs; all eight cost an occupancy step)
+        auto dy_piece = [&](int j) -> u32x4 {
+            const int px = pl + j * 32, tyc = min(px >> 4, vy - 1), txc = min(px & 15, vx - 1);
+            return *reinterpret_cast<const u32x4*>(dy + (int64_t)((b * H + y0 + tyc) * W + x0p + txc) * lddy + g * V);
+        };
+        u32x4 raw[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) raw[j] = dy_piece(j);
         __syncthreads();
         for (int idx = tid; idx < HALO_PIX * CIN; idx += 256) {
             int q = idx / CIN, ci = idx - q * CIN;
@@ -1964,9 +1976,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_v3(const T* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int px = pl + j * 32, ty = px >> 4, tx = px & 15;
-            if (ty < vy && tx < vx) {
+            {
+                const bool in = ty < vy && tx < vx;
                 float d[V];
-                uh_load<T, V>(dy + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * lddy + g * V, d);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    d[2 * q] = in ? __builtin_bit_cast(float, raw[j % DEPTH][q] << 16) : 0.f;
+                    d[2 * q + 1] = in ? __builtin_bit_cast(float, raw[j % DEPTH][q] & 0xffff0000u) : 0.f;
+                }
+                if (j + DEPTH < 8) raw[j % DEPTH] = dy_piece(j + DEPTH);      // refill the slot just consumed
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
