@@ -1038,6 +1038,29 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
     for (int i = 0; i < V; ++i) { esc[i] = ep_scale ? ep_scale[g * V + i] : 1.f; esh[i] = ep_scale ? ep_shift[g * V + i] : 0.f; }
     float cnt = 0.f;
     bool have_k = false;
+    // the image halo of the NEXT tile is fetched into registers while the current tile is computed, so a workgroup does
+    // not sit through an HBM round trip between its two barriers on every tile
+    constexpr int NX = (HALO_PIX * CIN + 255) / 256;
+    float xr[NX];
+    auto fetch_halo = [&](int tile_) {
+        int t = tile_;
+        const int txt = t % tilesX; t /= tilesX;
+        const int tyt = t % tilesY;
+        const int b = t / tilesY;
+        const int y0 = tyt * TILE, x0p = txt * TILE;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = tid + k * 256;
+            const int q = idx / CIN, ci = idx - q * CIN;
+            const int hy = q / HALO_W, hx = q - hy * HALO_W;
+            const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+            const bool in = idx < HALO_PIX * CIN && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gx, 0), W - 1);
+            const float v = uh_to_f32(x[(int64_t)((b * H + gyc) * W + gxc) * ldx + (idx < HALO_PIX * CIN ? ci : 0)]);
+            xr[k] = in ? v : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntile) fetch_halo(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
@@ -1046,15 +1069,11 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
         const int y0 = tyt * TILE, x0p = txt * TILE;
         const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
         __syncthreads();
-        for (int idx = tid; idx < HALO_PIX * CIN; idx += 256) {
-            int q = idx / CIN, ci = idx - q * CIN;
-            int hy = q / HALO_W, hx = q - hy * HALO_W;
-            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
-            xs[idx] = v;
-        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+            if (tid + k * 256 < HALO_PIX * CIN) xs[tid + k * 256] = xr[k];
         __syncthreads();
+        if (tile + (int)gridDim.x < ntile) fetch_halo(tile + gridDim.x);
         float out[8][V];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
