@@ -1468,23 +1468,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
         const int b = t / tilesY;
         const int y0 = tyt * TH, x0p = txt * TILE;
         __syncthreads();   // previous tile's reads finished
-        for (int idx = tid; idx < XPIX * PPP; idx += 256) {
-            int q = idx / PPP, part = idx - q * PPP;
-            int hy = q / HALO_W, hx = q - hy * HALO_W;
-            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W && part * VEC < xleft)
-                v = *reinterpret_cast<const u32x4*>(xsrc + (int64_t)((b * H + gy) * W + gx) * ldx + part * VEC);
-            *reinterpret_cast<u32x4*>(xs + lds_addr(q, part * 16)) = v;
+        // Staging loads are branch-free (clamped to a valid pixel / piece, zeroed afterwards) and go in batches of four:
+        // with the load inside `if (in range)` each one was waited for before the next was issued.
+        constexpr int SB = 4;
+        for (int base = 0; base < XPIX * PPP; base += SB * 256) {
+            u32x4 v[SB];
+            bool ok[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = min(base + tid + k * 256, XPIX * PPP - 1);
+                const int q = idx / PPP, part = idx - q * PPP;
+                const int hy = q / HALO_W, hx = q - hy * HALO_W;
+                const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+                ok[k] = gy >= 0 && gy < H && gx >= 0 && gx < W && part * VEC < xleft;
+                const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gx, 0), W - 1), pc = part * VEC < xleft ? part : 0;
+                v[k] = *reinterpret_cast<const u32x4*>(xsrc + (int64_t)((b * H + gyc) * W + gxc) * ldx + pc * VEC);
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = base + tid + k * 256;
+                if (idx < XPIX * PPP) {
+                    const int q = idx / PPP, part = idx - q * PPP;
+                    *reinterpret_cast<u32x4*>(xs + lds_addr(q, part * 16)) = ok[k] ? v[k] : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
         }
-        for (int idx = tid; idx < DPIX * PPP; idx += 256) {
-            int q = idx / PPP, part = idx - q * PPP;
-            int ty = q / TILE, tx = q - ty * TILE;
-            int gy = y0 + ty, gx = x0p + tx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gy < H && gx < W && part * VEC < dleft)
-                v = *reinterpret_cast<const u32x4*>(dsrc + (int64_t)((b * H + gy) * W + gx) * lddy + part * VEC);
-            *reinterpret_cast<u32x4*>(ds + lds_addr(q, part * 16)) = v;
+        for (int base = 0; base < DPIX * PPP; base += SB * 256) {
+            u32x4 v[SB];
+            bool ok[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = min(base + tid + k * 256, DPIX * PPP - 1);
+                const int q = idx / PPP, part = idx - q * PPP;
+                const int ty = q / TILE, tx = q - ty * TILE;
+                const int gy = y0 + ty, gx = x0p + tx;
+                ok[k] = gy < H && gx < W && part * VEC < dleft;
+                const int gyc = min(gy, H - 1), gxc = min(gx, W - 1), pc = part * VEC < dleft ? part : 0;
+                v[k] = *reinterpret_cast<const u32x4*>(dsrc + (int64_t)((b * H + gyc) * W + gxc) * lddy + pc * VEC);
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = base + tid + k * 256;
+                if (idx < DPIX * PPP) {
+                    const int q = idx / PPP, part = idx - q * PPP;
+                    *reinterpret_cast<u32x4*>(ds + lds_addr(q, part * 16)) = ok[k] ? v[k] : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
         }
         __syncthreads();
 
