@@ -927,6 +927,7 @@ class OutConv1x1Fn(Function):
                  B * H * W, Cin, ncls, _dt(x), _stream())
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
+        ctx.params = (weight, bias)
         return logits
 
     @staticmethod
@@ -942,10 +943,23 @@ class OutConv1x1Fn(Function):
             LIB.call("uh_conv1x1_dgrad", dl.data_ptr(), w2.data_ptr(), dx.data_ptr(), Cin, n, Cin, ncls, _dt(x), _stream())
         nbytes = LIB.query("uh_conv1x1_wgrad_ws_bytes", n, Cin, ncls)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        dw = torch.empty((ncls, Cin), dtype=torch.float32, device=x.device)
-        db = torch.empty(ncls, dtype=torch.float32, device=x.device)
+        # straight into the optimizer's flat gradient buffer when the parameter is registered there (FusedRMSprop) and its
+        # [n_classes][Cin] plane is dense -- a 1x1 filter has the same memory order in contiguous and channels_last layout
+        weight, bias = ctx.params
+        (dwb, cb_w), (dbb, cb_b) = _grad_buffer(weight), _grad_buffer(bias)
+        direct = cb_w is not None and cb_b is not None and dwb.stride(0) == Cin and dwb.stride(1) == 1 and \
+            dbb.is_contiguous() and dwb.dtype == torch.float32 and dbb.dtype == torch.float32
+        if direct:
+            dw, db = dwb, dbb
+        else:
+            dw = torch.empty((ncls, Cin), dtype=torch.float32, device=x.device)
+            db = torch.empty(ncls, dtype=torch.float32, device=x.device)
         LIB.call("uh_conv1x1_wgrad", dl.data_ptr(), x.data_ptr(), pixel_ld(x), dw.data_ptr(), db.data_ptr(),
                  ws.data_ptr(), nbytes, n, Cin, ncls, _dt(x), _stream())
+        if direct:
+            cb_w()
+            cb_b()
+            return dx, None, None
         return dx, dw.view(ctx.wshape), db
 
 
