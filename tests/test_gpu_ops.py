@@ -120,7 +120,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("B,h,w,C,Ho,Wo", [(2, 32, 32, 64, 64, 64), (2, 12, 19, 64, 25, 39), (1, 8, 9, 8, 17, 19),
                                            (2, 1, 1, 16, 2, 2), (1, 5, 7, 3, 10, 14), (2, 4, 4, 512, 8, 8),
                                            (1, 40, 33, 16, 81, 67), (8, 64, 64, 64, 128, 128), (2, 2, 2, 8, 4, 4),
-                                           (1, 3, 2, 8, 7, 5), (4, 128, 96, 64, 256, 192), (1, 2, 9, 8, 4, 18)])
+                                           (1, 3, 2, 8, 7, 5), (4, 128, 96, 64, 256, 192), (1, 2, 9, 8, 4, 18),
+                                           (1, 6, 7, 24, 12, 14), (2, 5, 3, 48, 13, 9), (1, 7, 7, 40, 14, 14)])   # channel groups not a power of two
 def test_upsample_bilinear_pad(dtype, B, h, w, C, Ho, Wo):
     from unet_amd import ops
     dev = _dev()
