@@ -195,16 +195,37 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < V; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
     }
+    if constexpr (HOIST) {
+        // the grid stride is a multiple of G: this thread keeps its channel group and walks pixels p0, p0 + pstep, ... --
+        // no 64-bit division per trip, and U branch-free (clamped) loads are in flight before the first is used
+        constexpr int U = 4;
+        const int64_t pstep = ((int64_t)gridDim.x * blockDim.x) / G;
+        const int c = (int)(first % G) * V;
+        // a thread's U pixels are neighbours (slot * U + u), so that the loads of one trip stay within a few KB
+        for (int64_t slot = first / G; slot * U < npix; slot += pstep) {
+            const int64_t p = slot * U;
+            float v[U][V];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t q = p + u < npix ? p + u : npix - 1;
+                uh_load<T, V>(y + q * ldy + c, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) v[u][i] = uh_relu(fmaf(v[u][i], sc[i], sh[i]));
+                if (p + u < npix) uh_store<T, V>(z + (p + u) * ldz + c, v[u]);
+            }
+        }
+        return;
+    }
     for (int64_t idx = first; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int64_t p = idx / G;
         int c = (int)(idx - p * G) * V;
         float v[V];
         uh_load<T, V>(y + p * ldy + c, v);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            if constexpr (HOIST) v[i] = uh_relu(fmaf(v[i], sc[i], sh[i]));
-            else v[i] = uh_relu(fmaf(v[i], scale[c + i], shift[c + i]));
-        }
+        for (int i = 0; i < V; ++i) v[i] = uh_relu(fmaf(v[i], scale[c + i], shift[c + i]));
         uh_store<T, V>(z + p * ldz + c, v);
     }
 }
