@@ -8,7 +8,9 @@ UNet 1x512x512 -> 1).
 One step = train.py:113-159 of the reference on one resident synthetic batch: forward (bf16 activations,
 fp32 accumulate / statistics / master weights), BCE + Dice + 0.25*boundary loss, NaN check, backward,
 (RCCL gradient all-reduce when N > 1), clip_grad_norm_(1.0), RMSprop.  N = 1 runs BASELINE config 2
-(UNet(1,1,bilinear=True), batch 8); N > 1 keeps 8 images per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+(UNet(1,1,bilinear=True), batch 8); N > 1 keeps 8 images per GPU (weak scaling) unless --global-batch G is given:
+then every rank takes G / N images (strong scaling; BASELINE config 3 = --global-batch 32 on 8 GPUs).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -26,6 +28,13 @@ FWD_GFLOP_PER_IMAGE = {True: 319.237, False: 384.735}      # keyed by `bilinear`
 TRAIN_GFLOP_PER_IMAGE = {True: 957.41, False: 1153.90}     # fwd + dgrad + wgrad - dgrad(stem)
 MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+TRAFFIC_PROFILE = "r02_hbm_traffic_pmc.json"               # HBM bytes per launch from the PMC passes (profiles/README.md)
+
+
+def source_sha256(name: str) -> str:
+    import hashlib
+    path = os.path.join(ROOT, "unet-medical-image-contour-segmentation_amd", "csrc", name)
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
 
 
 def parse():
@@ -34,6 +43,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed GLOBAL batch split evenly over the ranks (strong scaling; BASELINE config 3: 32); 0 = --batch per GPU")
+    ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics of the global batch (SURVEY 8e option 2)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity path) instead of bf16")
     ap.add_argument("--convt", action="store_true", help="transposed-conv upsample variant (config 5)")
@@ -53,29 +65,38 @@ def parse():
 
 
 def cpu_baseline(size: int):
-    """The CPU oracle (oracle/step_ref.py: stock fp32 PyTorch restatement of train.py:113-159, pinned to the
-    reference's golden fixtures) timed on this host: BASELINE config 1 = batch 2, 1x512x512, fp32."""
+    """The CPU oracle (oracle/step_ref.py: stock PyTorch restatement of train.py:113-159, pinned to the reference's golden
+    fixtures) timed on this host: BASELINE config 1 = batch 2, 1x512x512; fp32 (amp=False, the parity leg) and CPU bf16
+    autocast (= the reference CLI's default --amp on a CUDA-less host, train.py:116,233).  1 warm-up + best of 3 each
+    (SURVEY.md 8d)."""
     from oracle import step_ref as S
     from oracle import unet_ref as U
     # the GPU box gives one GPU a share of 16 host cores (the machine shows 256): oversubscribing slows oneDNN down
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     torch.manual_seed(0)
-    st = U.init_state(1, 1, True, seed=0)
     g = torch.Generator().manual_seed(1)
     images = torch.rand(2, 1, size, size, generator=g)
     masks = torch.randint(0, 3, (2, size, size), generator=g)
-    opt = None
-    st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True)      # warm-up
-    best = float("inf")
-    nsteps = 2
-    for _ in range(nsteps):
-        t0 = time.perf_counter()
-        st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": round(2.0 / best, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+    nsteps = 3
+    legs = {}
+    for name, amp in (("fp32", False), ("bf16_autocast", True)):
+        st = U.init_state(1, 1, True, seed=0)
+        opt = None
+        st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True, amp=amp)      # warm-up
+        best = float("inf")
+        for _ in range(nsteps):
+            t0 = time.perf_counter()
+            st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True, amp=amp)
+            best = min(best, time.perf_counter() - t0)
+        legs[name] = {"images_per_sec": round(2.0 / best, 4), "s_per_step": round(best, 3)}
+    return {"value": legs["fp32"]["images_per_sec"], "unit": "images/sec", "cores": torch.get_num_threads(),
             "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"oracle/step_ref.train_step, UNet(1,1,bilinear=True) fp32, batch 2 x 1x{size}x{size}, "
-                      f"1 warm-up + best of {nsteps} steps ({best:.2f} s/step)"}
+            "sample": f"oracle/step_ref.train_step, UNet(1,1,bilinear=True) fp32 (amp=False), batch 2 x 1x{size}x{size}, "
+                      f"1 warm-up + best of {nsteps} steps ({legs['fp32']['s_per_step']:.2f} s/step)",
+            "bf16_autocast": {"value": legs["bf16_autocast"]["images_per_sec"], "unit": "images/sec",
+                              "sample": f"same step under torch.autocast('cpu', bfloat16) (the reference CLI default), "
+                                        f"1 warm-up + best of {nsteps} ({legs['bf16_autocast']['s_per_step']:.2f} s/step); "
+                                        "timing only, the fixtures pin the fp32 leg"}}
 
 
 def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4):
@@ -106,7 +127,7 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
         for i in range(steps):
             im, mk = train[i % len(train)]
             stepper.step(im.to(dev), mk.to(dev))
-        d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp)
+        d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp, postprocess=False)
         out[name] = round(float(d), 4)
     return out
 
@@ -146,9 +167,17 @@ def main():
     model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
     stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream, cc_loss=args.cc_loss,
-                                   fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact")
+                                   fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
     g = torch.Generator().manual_seed(1 + rank)
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        args.batch = args.global_batch // world
     B, S = args.batch, args.size
+    sync = stepper.optimizer.sync
+    if sync is not None:
+        sync.time_exposed = True
     images = torch.rand(B, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     masks = torch.randint(0, 3, (B, S, S), generator=g).to(dev)
 
@@ -166,6 +195,9 @@ def main():
         last = stepper.step(images, masks)
     barrier()
     elapsed = time.perf_counter() - t0
+    exposed = sync.exposed_ms()[-args.steps:] if sync is not None else None
+    if sync is not None:
+        sync.time_exposed = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -199,15 +231,22 @@ def main():
         # HBM bytes per launch of this kernel family from the PMC passes committed under profiles/ (rocprofv3 cannot be
         # driven from inside the process); null for configurations that were not profiled
         traffic = None
+        traffic_note = "not profiled for this configuration"
         try:
-            if amp and bilinear and B == 8 and S == 512:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-                traffic = tj.get(dom[0] + "_per_launch", {}).get("hbm_MB")
-                traffic = None if traffic is None else round(traffic * 1e6)
-        except Exception:
-            traffic = None
+            if amp and bilinear and B == 8 and S == 512 and not args.config4:
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
+                # the profile is stamped with the sha256 of the kernel source it was measured on: a stale profile (the
+                # kernels changed since) yields null instead of a number that no longer describes the binary
+                if tj.get("source_sha256", {}).get("conv3x3.hip") == source_sha256("conv3x3.hip"):
+                    traffic = tj.get(dom[0] + "_per_launch", {}).get("hbm_MB")
+                    traffic = None if traffic is None else round(traffic * 1e6)
+                    traffic_note = f"profiles/{TRAFFIC_PROFILE} (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                else:
+                    traffic_note = f"profiles/{TRAFFIC_PROFILE} is stale: conv3x3.hip changed since it was measured"
+        except Exception as e:
+            traffic, traffic_note = None, f"no usable traffic profile ({e.__class__.__name__})"
         roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
         # the layer the north-star names: the 256-channel DoubleConv (down2: 128->256->256 at 128x128, batch 8)
         try:
@@ -220,20 +259,32 @@ def main():
         out = {
             "metric": f"images/sec (train step) UNet {n_in}x{S}x{S}->{n_cls}",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16" if amp else ("f32 (3x3 fwd/dgrad as bf16x3 split products)" if args.bf16x3 else "f32"),
             "data": "synthetic",
             "config": {"workload": (f"UNet({n_in},{n_cls},bilinear={bilinear}{', depth 5' if args.config4 else ''}) train step "
                                     f"({'BCE' if n_cls == 1 else 'CE'}+Dice+boundary, clip 1.0, RMSprop), "
                                     f"{B} x {n_in}x{S}x{S} per GPU, global batch {B * world}"),
                        "parallelism": f"dp{world}", "global_batch": B * world, "per_gpu_batch": B,
-                       "bn": "per-rank batch statistics", "dice": "global-batch sums (all-reduced)"},
+                       "bn": "global-batch statistics (SyncBN)" if args.sync_bn else "per-rank batch statistics",
+                       "dice": "global-batch sums (all-reduced)"},
             "loss": round(loss, 6),
             "train_tflops_per_gpu": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3, 1),
             "conv_roofline_frac_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3 /
                                              (MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS), 4),
             "roofline": roof, "kernels": kernels,
         }
+        if world > 1:
+            import torch.distributed as dist
+            out["collective"] = {
+                "backend": dist.get_backend(), "world": dist.get_world_size(),
+                "grad_bytes": int(stepper.optimizer.flat_g.numel() * 4), "grad_buckets": len(sync.buckets),
+                # time the launch stream spent waiting for the gradient all-reduce in front of clip + RMSprop (two events
+                # around the waits, nothing else between them): what the overlap with the encoder backward did NOT hide
+                "exposed_allreduce_ms_per_step": round(sum(exposed) / max(len(exposed), 1), 4) if exposed else None,
+                "exposed_allreduce_ms_max": round(max(exposed), 4) if exposed else None,
+            }
         if world == 1 and not args.no_inference:
             # forward-only inference (model.eval(): running statistics folded into the conv epilogue)
             try:

@@ -105,7 +105,8 @@ int uh_conv3x3_wgrad_narrow(const void* dy, int lddy, int Cout, int Coutv, const
  * finalize: merge the conv's stat slabs (Chan's formula, double) -> mean, rstd = 1/sqrt(var_biased + eps),
  * scale = gamma*rstd, shift = beta - mean*scale; running stats (may be NULL) updated in place with
  * `momentum` and the UNBIASED variance (n = pixels per channel); *num_batches_tracked (int64 on the
- * device, may be NULL) += 1.  Slab rows whose pixel count is 0 are ignored.  m2_out (may be NULL): the merged
+ * device, may be NULL) += 1.  Slab rows whose pixel count is 0 are ignored; n == 0: use the sum of the rows' counts.
+ * m2_out (may be NULL): the merged
  * M2 = sum (y - mean)^2 per channel -- with (mean, M2, n) per rank as rows, a second call merges ranks (SyncBN). */
 int uh_bn_finalize(const float* stat_partials, int nslab, int C, int64_t n,
                    const float* gamma, const float* beta, float* running_mean, float* running_var,

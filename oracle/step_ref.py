@@ -66,14 +66,18 @@ def train_step(state: U.State, opt: Optional[Dict[str, Dict[str, torch.Tensor]]]
                images: torch.Tensor, masks: torch.Tensor, *, n_classes: int, bilinear: bool,
                depth: int = 4, lr: float = 1e-5, weight_decay: float = 1e-8,
                momentum: float = 0.999, gradient_clipping: float = 1.0,
-               boundary_weight_multiclass: float = 0.0):
-    """Returns (new_state, new_opt, info).  Pure: inputs are not mutated."""
+               boundary_weight_multiclass: float = 0.0, amp: bool = False):
+    """Returns (new_state, new_opt, info).  Pure: inputs are not mutated.
+    amp=True wraps forward + loss in torch.autocast('cpu', bfloat16) as train.py:116 does on a CUDA-less host (the
+    reference CLI's default, train.py:233; GradScaler is auto-disabled there).  The bf16 leg is a TIMING baseline
+    (bench.py cpu_baseline): the golden fixtures pin the fp32 leg only."""
     keys = U.param_keys(state)
     work = {k: (v.detach().clone().requires_grad_(True) if k in keys else v.detach().clone())
             for k, v in state.items()}
     new_buffers: U.State = {}
-    logits = U.unet_forward(images, work, bilinear, depth, training=True, new_buffers=new_buffers)
-    terms = seg_loss(logits, masks, n_classes, boundary_weight_multiclass)
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp):
+        logits = U.unet_forward(images, work, bilinear, depth, training=True, new_buffers=new_buffers)
+        terms = seg_loss(logits, masks, n_classes, boundary_weight_multiclass)
     loss = terms["loss"]
     if torch.isnan(loss).any():
         raise RuntimeError("Fatal: NaN loss detected!")           # train.py:151

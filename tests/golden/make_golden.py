@@ -15,7 +15,8 @@ model/loss modules through the statement sequence of train.py:113-159 using stoc
 Fixture list: G1 DoubleConv, G2 Down, G3 Up bilinear (+odd-size pad),
 G4 Up convT, G5 OutConv, G6 Dice, G7 boundary_loss, G8 UNet_T 3-step trajectories,
 G9 full UNet scalars, G10 eval-mode logits/masks, G11 depth-5 net from reference parts,
-G12 utils/data_loading.BasicDataset items on synthetic PNG files.
+G12 utils/data_loading.BasicDataset items on synthetic PNG files,
+G13 full-width config-4 / config-5 nets on small images (scalars + first logits).
 """
 import os
 import sys
@@ -317,17 +318,6 @@ def g11_depth5():
     save("g11_depth5_multiclass", **rec)
 
 
-if __name__ == "__main__":
-    g1_to_g5()
-    g6_dice()
-    g7_boundary()
-    g8_unet_t()
-    g10_eval()
-    g11_depth5()
-    g9_full_unet()
-    g12_data_loading()
-
-
 def g12_data_loading():
     """utils/data_loading.py: three synthetic grey images + {0,128,255} masks written as PNG, read back through the
     reference's BasicDataset (augment on, scale 1.0 and 0.5).  Stores the raw arrays and every item."""
@@ -360,3 +350,45 @@ def g12_data_loading():
         ds = BasicDataset(os.path.join(d, "imgs"), os.path.join(d, "masks"), 1.0, augment=False)
         rec["noaug.len"] = np.array(len(ds))
     save("g12_data_loading", **rec)
+
+
+def g13_full_width():
+    """Full-width nets on small images (weights from torch.manual_seed, so no state dict is stored): BASELINE config 5's
+    UNet(1,1,bilinear=False) on 2x1x64x64 and config 4's depth-5 bilinear net (64..2048) on 1x3x64x64 with CE + multiclass
+    Dice + 0.2 * boundary (4-D path); 2 steps each, logits of step 0 + every loss term and the gradient norm."""
+    rec = {}
+    torch.manual_seed(0)
+    m = UNet(1, 1, bilinear=False)
+    batches = [synth_batch(500 + s, 2, 1, 64, 64) for s in range(2)]
+    r = ref_train_steps(m, [b[0] for b in batches], [b[1] for b in batches], 1, lr=1e-5, record_grads=False)
+    rec.update({"cfg5." + k: v for k, v in r.items() if not k.startswith("sd")})
+    torch.manual_seed(0)
+    m = UNet(1, 1, bilinear=False)
+    m.train()
+    with torch.no_grad():
+        rec["cfg5.s0.logits"] = npy(m(batches[0][0]))
+    torch.manual_seed(0)
+    w = [64, 128, 256, 512, 1024, 2048]
+    m = Depth5(3, 4, w)
+    batches = [synth_batch(600 + s, 1, 3, 64, 64, nmask=4) for s in range(2)]
+    r = ref_train_steps(m, [b[0] for b in batches], [b[1] for b in batches], 4, lr=1e-5, record_grads=False, boundary_mc=0.2)
+    rec.update({"cfg4." + k: v for k, v in r.items() if not k.startswith("sd")})
+    torch.manual_seed(0)
+    m = Depth5(3, 4, w)
+    m.train()
+    with torch.no_grad():
+        rec["cfg4.s0.logits"] = npy(m(batches[0][0]))
+    rec["note"] = np.array("weights torch.manual_seed(0) then ctor; data synth_batch(500+s,2,1,64,64) / synth_batch(600+s,1,3,64,64,nmask=4)")
+    save("g13_full_width", **rec)
+
+
+if __name__ == "__main__":
+    g1_to_g5()
+    g6_dice()
+    g7_boundary()
+    g8_unet_t()
+    g10_eval()
+    g11_depth5()
+    g9_full_unet()
+    g12_data_loading()
+    g13_full_width()

@@ -1,0 +1,326 @@
+"""Parity at the sizes the benchmark runs ("the code path the benchmark times is not the code path the suite
+checks"): the reference's own 512x512 scalars (fixture G9), full-width config-4 / config-5 nets against the reference
+(fixture G13) and the CPU oracle, one batch-8 512x512 bf16 step against the HIP fp32 path at the same size, and the
+reference's train loop restated literally (stock torch.optim.RMSprop / GradScaler / clip_grad_norm_, train.py:80-85,
+113-159) on the drop-in modules.  Tolerances: step 0 = BASELINE north_star (1e-3 relative fp32; loss terms 1e-4); later
+steps sit behind RMSprop's sign-like first updates and use the allowances of the G8 trajectories (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; the product path has no CPU fallback")
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def close(got, want, tol, what):
+    got, want = float(got), float(want)
+    assert abs(got - want) <= tol * abs(want), f"{what}: {got!r} vs reference {want!r} (rel {abs(got - want) / abs(want):.2e} > {tol:.0e})"
+
+
+def check(a, b, tol, what, l2=False):
+    a64, b64 = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    if l2:
+        err, bound = float((a64 - b64).norm()), tol * float(b64.norm())
+    else:
+        err, bound = float((a64 - b64).abs().max()), tol * float(b64.abs().max())
+    assert err <= bound, f"{what}: error {err:.3e} > {bound:.3e}"
+
+
+# ------------------------------------------------------------------------------------------ G9: the reference at 512x512
+def test_g9_full_unet_512_reference_scalars():
+    """UNet(1,1,bilinear=True), the seeded 2x1x512x512 batch, fp32, 3 steps (make_golden.g9_full_unet: the reference's own
+    modules driven through train.py:113-159).  At this size every conv runs the persistent multi-tile kernels (2048 tiles
+    per launch at 512x512) and backward-weights its full pixel-range split -- the dispatch branches bench.py times."""
+    import unet_amd
+    dev = _dev()
+    r = load_golden("g9_unet_full_scalars")
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(2, 1, 512, 512, generator=g).to(dev)
+    masks = torch.randint(0, 3, (2, 512, 512), generator=g).to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=False)
+    for s in range(3):
+        t = stepper.step(images, masks)
+        first = s == 0
+        close(t["bce"], r[f"s{s}.bce"], 1e-4 if first else 3e-3, f"bce s{s}")
+        close(t["dice"], r[f"s{s}.dice"], 1e-4 if first else 3e-3, f"dice s{s}")
+        close(t["boundary"], r[f"s{s}.boundary"], 1e-4 if first else 2e-2, f"boundary s{s}")
+        close(t["loss"], r[f"s{s}.loss"], 1e-4 if first else 3e-3, f"loss s{s}")
+        close(t["grad_norm"], r[f"s{s}.grad_norm"], 1e-3 if first else 3e-2, f"grad_norm s{s}")
+
+
+# ------------------------------------------------------------------------------------------ config 2's exact shape
+def test_b8_512_bf16_step_matches_fp32_path_at_the_same_size():
+    """BASELINE config 2 as benchmarked (UNet(1,1,bilinear), 8 x 1x512x512, bf16 activations) against the HIP fp32 path on
+    the same batch from the same weights -- the fp32 path itself is pinned to the reference at 512x512 by G9."""
+    import unet_amd
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(8, 1, 512, 512, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    masks = torch.randint(0, 3, (8, 512, 512), generator=g).to(dev)
+    out = {}
+    for amp in (False, True):
+        torch.manual_seed(0)
+        model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp)
+        t = stepper.step(images, masks)
+        torch.cuda.synchronize()
+        out[amp] = {k: (v.detach().float().clone() if torch.is_tensor(v) else v) for k, v in t.items()}
+        del stepper, model
+    f32, b16 = out[False], out[True]
+    check(b16["logits"], f32["logits"], 8e-2, "bf16 logits vs fp32 (L2)", l2=True)
+    close(b16["loss"], f32["loss"], 2e-2, "bf16 loss")
+    close(b16["bce"], f32["bce"], 2e-2, "bf16 bce")
+    close(b16["dice"], f32["dice"], 2e-2, "bf16 dice")
+    close(b16["grad_norm"], f32["grad_norm"], 1e-1, "bf16 grad_norm")
+    assert torch.isfinite(b16["logits"]).all()
+
+
+# ------------------------------------------------------------------------------------------ G13: full-width config 4 / 5
+def test_g13_config5_convt_exact_fp32_with_cc_loss():
+    """UNet(1,1,bilinear=False) (64..1024, ConvTranspose), exact fp32 (not bf16x3), 2x1x64x64, with the
+    connected_component_loss term switched on (BASELINE config 5): logits / loss terms / gradient norm against the
+    reference's own modules; the cc term adds a non-negative VALUE and changes nothing else."""
+    import unet_amd
+    dev = _dev()
+    r = load_golden("g13_full_width")
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=False).to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=False, cc_loss=True, fp32_mode="exact")
+    for s in range(2):
+        g = torch.Generator().manual_seed(500 + s)
+        im = torch.rand(2, 1, 64, 64, generator=g).to(dev)
+        mk = torch.randint(0, 3, (2, 64, 64), generator=g).to(dev)
+        t = stepper.step(im, mk)
+        first = s == 0
+        if first:
+            check(t["logits"], r["cfg5.s0.logits"], 1e-3, "cfg5 logits")
+        close(t["bce"], r[f"cfg5.s{s}.bce"], 1e-4 if first else 3e-3, f"cfg5 bce s{s}")
+        close(t["dice"], r[f"cfg5.s{s}.dice"], 1e-4 if first else 3e-3, f"cfg5 dice s{s}")
+        close(t["boundary"], r[f"cfg5.s{s}.boundary"], 1e-4 if first else 2e-2, f"cfg5 boundary s{s}")
+        cc = float(t["cc"])
+        assert cc >= 0.0
+        close(float(t["loss"]) - cc, r[f"cfg5.s{s}.loss"], 1e-4 if first else 3e-3, f"cfg5 loss s{s}")
+        close(t["grad_norm"], r[f"cfg5.s{s}.grad_norm"], 2e-3 if first else 3e-2, f"cfg5 grad_norm s{s}")
+
+
+def test_g13_config4_depth5_full_width():
+    """BASELINE config 4's network at full width (64..2048/2, the 2048-channel two-source K loop in up1) on 1x3x64x64:
+    CE + multiclass Dice + 0.2 * boundary (4-D path) against the reference-composed Depth5."""
+    import unet_amd
+    dev = _dev()
+    r = load_golden("g13_full_width")
+    torch.manual_seed(0)
+    model = unet_amd.UNetDepth(3, 4, True, widths=(64, 128, 256, 512, 1024, 2048)).to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=False)
+    for s in range(2):
+        g = torch.Generator().manual_seed(600 + s)
+        im = torch.rand(1, 3, 64, 64, generator=g).to(dev)
+        mk = torch.randint(0, 4, (1, 64, 64), generator=g).to(dev)
+        model.train()
+        t = unet_amd.train_step(model, stepper.optimizer, im, mk, amp=False, boundary_weight=0.2)
+        first = s == 0
+        if first:
+            check(t["logits"], r["cfg4.s0.logits"], 1e-3, "cfg4 logits")
+        close(t["ce"], r[f"cfg4.s{s}.ce"], 1e-4 if first else 5e-3, f"cfg4 ce s{s}")
+        close(t["dice"], r[f"cfg4.s{s}.dice"], 1e-4 if first else 5e-3, f"cfg4 dice s{s}")
+        close(t["boundary"], r[f"cfg4.s{s}.boundary"], 1e-4 if first else 3e-2, f"cfg4 boundary s{s}")
+        close(t["loss"], r[f"cfg4.s{s}.loss"], 1e-4 if first else 5e-3, f"cfg4 loss s{s}")
+        # bottleneck 2x2 at batch 1: BatchNorm over 4 samples, the worst-conditioned case in the suite
+        close(t["grad_norm"], r[f"cfg4.s{s}.grad_norm"], 5e-3 if first else 1e-1, f"cfg4 grad_norm s{s}")
+
+
+def test_config4_full_width_gradients_vs_oracle():
+    """Same net, one step against oracle/step_ref.train_step: per-parameter gradients (L2, conditioning allowance of
+    test_full_unet_step_vs_oracle_fp32)."""
+    import unet_amd
+    from oracle import step_ref as S
+    dev = _dev()
+    torch.manual_seed(0)
+    model = unet_amd.UNetDepth(3, 4, True, widths=(64, 128, 256, 512, 1024, 2048))
+    g = torch.Generator().manual_seed(600)
+    im = torch.rand(1, 3, 64, 64, generator=g)
+    mk = torch.randint(0, 4, (1, 64, 64), generator=g)
+    st = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    _, _, info = S.train_step(st, None, im, mk, n_classes=4, bilinear=True, depth=5, boundary_weight_multiclass=0.2)
+    model = model.to(dev)
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=False)
+    model.train()
+    t = unet_amd.train_step(model, stepper.optimizer, im.to(dev), mk.to(dev), amp=False, boundary_weight=0.2)
+    check(t["logits"], info["logits"], 1e-3, "cfg4 logits vs oracle")
+    close(t["loss"], info["loss"], 1e-4, "cfg4 loss vs oracle")
+    coef = float(S.clip_coef(info["grad_norm"], 1.0))
+    bad = []
+    for k, p in model.named_parameters():
+        a, b = stepper.optimizer.grad_of(p).double().cpu(), (info["grads"][k] * coef).double()
+        e = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if e > 5e-2:
+            bad.append((k, e))
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------ the reference's loop, literally
+def _reference_loop(model, batches, device, amp, lr=1e-5, weight_decay=1e-8, momentum=0.999, gradient_clipping=1.0):
+    """train.py:80-85 and 113-159 restated statement by statement on `model` (any nn.Module with the reference surface)."""
+    import unet_amd
+    optimizer = torch.optim.RMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum, foreach=True)
+    grad_scaler = torch.amp.GradScaler(enabled=amp)
+    criterion = nn.CrossEntropyLoss() if model.n_classes > 1 else nn.BCEWithLogitsLoss()
+    model.train()
+    log = []
+    for images, true_masks in batches:
+        assert images.shape[1] == model.n_channels
+        images = images.to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
+        true_masks = true_masks.to(device=device, dtype=torch.long)
+        with torch.autocast(device.type, enabled=amp):
+            masks_pred = model(images)
+            if model.n_classes == 1:
+                true_masks //= 2
+                loss = criterion(masks_pred.squeeze(1), true_masks.float())
+                loss += unet_amd.dice_loss(torch.sigmoid(masks_pred.squeeze(1)), true_masks.float(), multiclass=False)
+                loss += 0.25 * unet_amd.boundary_loss(masks_pred.squeeze(1), true_masks.float(), edge_width=51, edge_weight=15)
+            else:
+                loss = criterion(masks_pred, true_masks)
+                loss += unet_amd.dice_loss(F.softmax(masks_pred, dim=1).float(),
+                                           F.one_hot(true_masks, model.n_classes).permute(0, 3, 1, 2).float(), multiclass=True)
+        if torch.isnan(loss).any():
+            raise RuntimeError("Fatal: NaN loss detected!")
+        optimizer.zero_grad(set_to_none=True)
+        grad_scaler.scale(loss).backward()
+        grad_scaler.unscale_(optimizer)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clipping)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()} if not log else None
+        grad_scaler.step(optimizer)
+        grad_scaler.update()
+        log.append({"logits": masks_pred.detach().float(), "loss": loss.detach().float(), "grad_norm": gn.detach(), "grads": grads})
+    return log
+
+
+@pytest.mark.parametrize("name,args,ncls", [("g8_unet_t_bilinear", (1, 1, True), 1), ("g8_unet_t_convt", (1, 1, False), 1),
+                                            ("g8_unet_t_multiclass", (3, 4, True), 4)])
+def test_reference_loop_with_stock_optimizer_reproduces_g8(name, args, ncls):
+    """"train.py's optimizer step drop-in unchanged": stock optim.RMSprop(foreach=True), GradScaler(enabled=False),
+    nn.BCEWithLogitsLoss / CrossEntropyLoss, clip_grad_norm_ on unet_amd.UNet_T -- no FusedRMSprop, no TrainStepper -- must
+    reproduce the reference's 3-step trajectory (fixture G8) at the tolerances of test_gpu_parity._run_traj."""
+    import unet_amd
+    dev = _dev()
+    r = load_golden(name)
+    model = unet_amd.UNet_T(*args).to(dev)
+    model.load_state_dict({k[4:]: T(v) for k, v in r.items() if k.startswith("sd0.")})
+    nsteps = sum(1 for k in r if k.endswith(".images"))
+    batches = [(T(r[f"s{s}.images"]), T(r[f"s{s}.masks"])) for s in range(nsteps)]
+    log = _reference_loop(model, batches, dev, amp=False)
+    for s, rec in enumerate(log):
+        first = s == 0
+        check(rec["logits"], r[f"s{s}.logits"], 1e-3 if first else 2e-2, f"logits s{s}")
+        close(rec["loss"], r[f"s{s}.loss"], 1e-4 if first else 3e-3, f"loss s{s}")
+        close(rec["grad_norm"], r[f"s{s}.grad_norm"], 1e-3 if first else 3e-2, f"grad_norm s{s}")
+        if first:
+            for k, gk in rec["grads"].items():
+                check(gk, r[f"s0.grad.{k}"], 2e-2, "grad " + k, l2=True)
+    final = {k[len(f"sd{nsteps}."):]: v for k, v in r.items() if k.startswith(f"sd{nsteps}.")}
+    lr = 1e-5
+    for k, v in model.state_dict().items():
+        if "num_batches" in k:
+            assert int(v) == int(final[k])
+            continue
+        a, b = v.detach().double().cpu(), torch.as_tensor(final[k]).double()
+        atol = 0.0 if "running" in k else 150 * lr       # see test_gpu_parity._run_traj
+        assert float((a - b).abs().max()) <= 5e-3 * float(b.abs().max()) + atol, k
+
+
+def test_reference_loop_under_autocast_and_gradscaler():
+    """The same loop with amp=True, as the reference CLI defaults to (train.py:233): torch.autocast('cuda') (fp16 autocast;
+    the HIP modules compute in bf16 under any autocast) + a live GradScaler.  The scaled backward must come back unscaled
+    and finite, and land close to the bf16 TrainStepper on the same batch."""
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(4, 64, seed=11)
+    torch.manual_seed(0)
+    m1 = unet_amd.UNet_S(1, 1, bilinear=True).to(dev)
+    log = _reference_loop(m1, [(im, mk), (im, mk)], dev, amp=True, lr=1e-4)
+    torch.manual_seed(0)
+    m2 = unet_amd.UNet_S(1, 1, bilinear=True).to(dev)
+    st = unet_amd.TrainStepper(m2, lr=1e-4, amp=True)
+    t = st.step(im.to(dev), mk.to(dev))
+    assert torch.isfinite(log[0]["loss"]) and torch.isfinite(log[1]["loss"])
+    close(log[0]["loss"], t["loss"], 2e-3, "autocast loop loss vs TrainStepper bf16")
+    close(log[0]["grad_norm"], t["grad_norm"], 5e-2, "autocast loop grad_norm vs TrainStepper bf16")
+    assert float(log[1]["loss"]) < float(log[0]["loss"]) + 1e-3      # the step did not blow the model up
+
+
+# ------------------------------------------------------------------------------------------ optimizer life cycle
+def test_second_stepper_on_the_same_model_takes_the_parameters_over():
+    """A second FusedRMSprop / TrainStepper on the same model: the first one's hooks must not steal the gradients of the
+    parameters that have no in-place writer (ConvTranspose2d weight / bias -- the reference's default bilinear=False)."""
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=9)
+    torch.manual_seed(0)
+    model = unet_amd.UNet_T(1, 1, bilinear=False).to(dev)
+    st1 = unet_amd.TrainStepper(model, lr=1e-3, amp=False)
+    st1.step(im.to(dev), mk.to(dev))
+    st2 = unet_amd.TrainStepper(model, lr=1e-3, amp=False)
+    assert st1.optimizer._closed and not st2.optimizer._closed
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    t = st2.step(im.to(dev), mk.to(dev))
+    torch.cuda.synchronize()
+    assert float(t["grad_norm"]) > 0
+    for k, p in model.named_parameters():
+        assert not torch.equal(p.detach(), before[k]), f"{k} did not move under the second stepper"
+        assert float(st2.optimizer.grad_of(p).abs().max()) > 0, f"{k}: zero gradient in the second stepper's buffer"
+    with pytest.raises(RuntimeError, match="after close"):
+        st1.optimizer.step()
+    # and a reference run from the same state with a single stepper gives the same second step
+    torch.manual_seed(0)
+    ref = unet_amd.UNet_T(1, 1, bilinear=False).to(dev)
+    s = unet_amd.TrainStepper(ref, lr=1e-3, amp=False)
+    s.step(im.to(dev), mk.to(dev))
+    t2 = s.step(im.to(dev), mk.to(dev))
+    # (st2 starts with fresh RMSprop state, so only the forward/backward of the second step is comparable)
+    close(t["loss"], t2["loss"], 1e-6, "second-step loss")
+    close(t["grad_norm"], t2["grad_norm"], 1e-5, "second-step gradient norm")
+
+
+def test_fused_optimizer_is_released_with_its_stepper():
+    import gc
+    import weakref
+    import unet_amd
+    from unet_amd import ops
+    dev = _dev()
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    st = unet_amd.TrainStepper(model, amp=False)
+    ref = weakref.ref(st.optimizer)
+    n_dst = len(ops.GRAD_DST)
+    del st
+    gc.collect()
+    assert ref() is None, "FusedRMSprop is kept alive by its parameter hooks"
+    assert len(ops.GRAD_DST) < n_dst
+
+
+def test_two_backwards_before_step_are_refused():
+    import unet_amd
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 32, seed=2)
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    opt = unet_amd.FusedRMSprop(model.parameters(), lr=1e-4)
+    model.train()
+    opt.zero_grad()
+    unet_amd.seg_loss(model(im.to(dev)), mk.to(dev), 1)["loss"].backward()
+    with pytest.raises(RuntimeError, match="gradient accumulation"):
+        unet_amd.seg_loss(model(im.to(dev)), mk.to(dev), 1)["loss"].backward()

@@ -99,3 +99,93 @@ def test_python_surface_uses_the_device_path():
     a = connected_component_loss(probs.to(dev), edge_distance=10, min_area=30, penalty_weight=0.1)
     b = connected_component_loss(probs, edge_distance=10, min_area=30, penalty_weight=0.1)
     assert isinstance(a, float) and abs(a - b) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Independent check: the device kernel against the numpy / scipy restatement in oracle/cc_loss_ref.py
+# (Moore border tracing + shoelace; a different algorithm from both csrc/ implementations), and OpenCV's documented corner
+# cases derived by hand.  Still PARITY UNPINNED (OpenCV is not installed): this removes the self-comparison only.
+# ------------------------------------------------------------------------------------------------------------------
+def _oracle(masks, ed, ma):
+    from oracle import cc_loss_ref as R
+    B = masks.shape[0]
+    # penalty_weight = B  ->  the function returns the plain penalty sum the C ABI reports in result[0]
+    return R.connected_component_loss(masks.astype(np.float32), edge_distance=ed, min_area=ma, penalty_weight=float(B))
+
+
+@pytest.mark.parametrize("kind", ["noise", "sparse", "blobs"])
+@pytest.mark.parametrize("B,H,W", [(3, 37, 53), (2, 64, 64), (1, 5, 9), (2, 128, 96)])
+def test_device_equals_numpy_oracle(kind, B, H, W):
+    from oracle import cc_loss_ref as R
+    rng = np.random.default_rng(B * 77 + H + 3 * W + len(kind))
+    m = _blob_masks(rng, B, H, W, kind)
+    for ed, ma in [(5, 7), (50, 1000), (16, 40)]:
+        d = _device(m, ed, ma)
+        want = _oracle(m, ed, ma)
+        ncont = sum(len(R.external_components(m[b])) for b in range(B))
+        assert d[1] == ncont, (d, ncont)
+        assert abs(d[0] - want) <= 1e-9 * max(1.0, abs(want)), (d, want)
+
+
+def test_python_surface_equals_numpy_oracle_on_probabilities():
+    from oracle import cc_loss_ref as R
+    from unet_amd.utils.connected_component_loss import connected_component_loss
+    dev = _dev()
+    rng = np.random.default_rng(21)
+    probs = torch.from_numpy(rng.random((3, 80, 112)).astype(np.float32))
+    probs = torch.nn.functional.avg_pool2d(probs[None], 7, 1, 3)[0] * 1.15
+    got = connected_component_loss(probs.to(dev), edge_distance=12, min_area=45, penalty_weight=0.1)
+    want = R.connected_component_loss(probs.numpy(), edge_distance=12, min_area=45, penalty_weight=0.1)
+    assert abs(got - want) < 1e-12, (got, want)
+
+
+def test_opencv_corner_cases_by_hand():
+    """cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + contourArea + boundingRect (connected_component_loss.py:28-56)
+    on the shapes where pixel count and polygon area differ most.  Each case: expected (penalty sum, external contours)."""
+    H, W = 48, 56
+    ma, ed = 20, 6
+
+    def run(m):
+        d = _device(m[None], ed, ma)
+        o = _oracle(m[None], ed, ma)
+        assert abs(d[0] - o) < 1e-12, (d, o)
+        return d
+
+    # 1-pixel-wide horizontal line of 30 pixels: the contour runs out and back along the same pixels -> area 0
+    m = np.zeros((H, W), bool); m[20, 10:40] = True
+    assert run(m) == (1.0, 1.0)
+    # 1-pixel-wide closed rectangular frame 21 x 31: the OUTER border polygon has area 20 * 30 = 600 (>= min_area), centre far
+    # from the edges -> no penalty; its inside is a hole, not a contour
+    m = np.zeros((H, W), bool); m[10, 10:41] = m[30, 10:41] = True; m[10:31, 10] = m[10:31, 40] = True
+    assert run(m) == (0.0, 1.0)
+    # two 5x5 squares touching only at a corner: ONE 8-connected component; outer border polygon = two 4x4 squares = 32
+    m = np.zeros((H, W), bool); m[10:15, 10:15] = True; m[15:20, 15:20] = True
+    assert run(m) == (0.0, 1.0)
+    # ... and 3x3 squares the same way: area 4 + 4 = 8 < 20 -> 1 - 8/20
+    m = np.zeros((H, W), bool); m[10:13, 10:13] = True; m[13:16, 13:16] = True
+    p, c = run(m); assert c == 1.0 and abs(p - 0.6) < 1e-15
+    # anti-diagonal staircase of single pixels: 8-connected, zero area
+    m = np.zeros((H, W), bool)
+    for i in range(9):
+        m[30 - i, 12 + i] = True
+    assert run(m) == (1.0, 1.0)
+    # nested: ring (outer 25x25) > hole > island 9x9 ring > hole > 3x3 dot.  RETR_EXTERNAL reports the outermost ring only:
+    # area 24 * 24 = 576
+    m = np.zeros((H, W), bool)
+    m[8:33, 8:33] = True; m[10:31, 10:31] = False
+    m[16:25, 16:25] = True; m[18:23, 18:23] = False
+    m[19:22, 19:22] = True
+    assert run(m) == (0.0, 1.0)
+    # a blob touching all four image borders (full frame of width 2): area (H-1)(W-1), bbox centre = image centre: d = min(28,
+    # 28, 24, 24) = 24 >= 6 -> no penalty, one contour; the background island inside is a hole
+    m = np.zeros((H, W), bool); m[:2] = m[-2:] = True; m[:, :2] = m[:, -2:] = True
+    assert run(m) == (0.0, 1.0)
+    # a large blob in the corner: area 15 * 11 = 165 >= 20, bbox (0,0,12,16): centre (6, 8) -> d = 6 is NOT < 6 -> no penalty;
+    # one pixel narrower: centre x = 11 // 2 = 5 -> d = 5 -> 1 - 5/6
+    m = np.zeros((H, W), bool); m[0:16, 0:12] = True
+    assert run(m) == (0.0, 1.0)
+    m = np.zeros((H, W), bool); m[0:16, 0:11] = True
+    p, c = run(m); assert c == 1.0 and abs(p - (1 - 5 / 6)) < 1e-15
+    # empty mask: no contours, zero loss; full mask: one contour of area (H-1)(W-1)
+    assert run(np.zeros((H, W), bool)) == (0.0, 0.0)
+    assert run(np.ones((H, W), bool)) == (0.0, 1.0)

@@ -34,9 +34,30 @@ SHAPES = [
 ]
 
 
+# More tiles than persistent workgroups (768 for 64-channel slabs, 512 for 128-channel ones; backward-weights: 512 pixel
+# ranges): every workgroup walks SEVERAL tiles, Chan-merges its BatchNorm moments across them and prefetches the next
+# tile's halo under the last K-chunk -- the code path bench.py times at 512x512.
+SHAPES_MULTITILE = [
+    (1, 448, 448, 64, 0, 64),        # 784 tiles > 768 workgroups (NBW = 1), 2 K-chunks per tile
+    (2, 320, 336, 64, 0, 128),       # 840 tiles x 1 slab > 512 workgroups (NBW = 2)
+    (1, 448, 448, 64, 64, 64),       # two-source K loop across tiles (the decoder's virtual concat)
+    (3, 250, 333, 128, 0, 64),       # odd sizes: partial tiles on both edges, 1008 tiles
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", SHAPES_MULTITILE)
+def test_conv3x3_multitile_fwd_stats_dgrad_wgrad(dtype, B, H, W, C0, C1, Cout):
+    _conv_case(dtype, B, H, W, C0, C1, Cout)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C0,C1,Cout", SHAPES)
 def test_conv3x3_fwd_dgrad_wgrad(dtype, B, H, W, C0, C1, Cout):
+    _conv_case(dtype, B, H, W, C0, C1, Cout)
+
+
+def _conv_case(dtype, B, H, W, C0, C1, Cout):
     from unet_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + C0 + Cout)

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     Moments m = {N, mean, block_sum(q, 2)};
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;            // unet_parts.py:16: BatchNorm2d bookkeeping
     if (sl != 0 || c >= C) return;
+    if (n <= 0.0) n = N;                        // caller did not know the pixel count: the counted total
     double var = m.m2 / n;                      // biased
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma[c], bt = beta[c];
@@ -134,7 +135,7 @@ extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int6
                               float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
                               float* m2_out, uh_stream stream) {
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
-    UH_REQUIRE(nslab > 0 && C > 0 && n > 0, "uh_bn_finalize: bad sizes");
+    UH_REQUIRE(nslab > 0 && C > 0 && n >= 0, "uh_bn_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
@@ -151,7 +152,7 @@ extern "C" int uh_bn_finalize_ld(const float* stat_partials, int nslab, int ldc,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
                                  float* m2_out, uh_stream stream) {
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize_ld: null pointer");
-    UH_REQUIRE(nslab > 0 && C > 0 && ldc >= C && n > 0, "uh_bn_finalize_ld: bad sizes");
+    UH_REQUIRE(nslab > 0 && C > 0 && ldc >= C && n >= 0, "uh_bn_finalize_ld: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, ldc, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,

@@ -36,6 +36,15 @@ def make_sum_reducer(group=None):
     return _reduce
 
 
+def global_batch(local_batch: int, group=None, device=None) -> int:
+    """Sum of the ranks' batch sizes (one tiny all-reduce + host read; used per step by SyncBN only)."""
+    if world_size(group) == 1:
+        return int(local_batch)
+    t = torch.tensor([int(local_batch)], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
 class BucketedGradSync:
     """All-reduce (sum; `average=True` for a mean) a flat gradient buffer in contiguous buckets as their slices become
     ready."""
@@ -63,11 +72,15 @@ class BucketedGradSync:
             self.members[b] += 1
         self.average = average
         self._use_avg = average and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.comm_stream = None
+        self.time_exposed = False
+        self.exposed = []
         self.reset()
 
     def reset(self):
         self.pending = list(self.members)
         self.launched = [False] * len(self.buckets)
+        self.side_event = [None] * len(self.buckets)     # latest side-stream event among a bucket's gradients
         self.handles = []
 
     def _launch(self, b: int):
@@ -76,17 +89,32 @@ class BucketedGradSync:
             return
         s, e = self.buckets[b]
         view = self.flat[s:e]
-        if self.flat.is_cuda:
-            from . import ops
-            if ops.WGRAD_STREAM is not None:      # weight gradients of this bucket may still be in flight there
-                torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-        h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        if self.flat.is_cuda:
+            # The collective is issued from a stream of its own that waits for (a) everything enqueued on the launch stream
+            # up to now (the bucket's BatchNorm / bias / ConvTranspose gradients) and (b) the LAST backward-weights kernel of
+            # this bucket on the side stream (an event recorded right behind it): the launch stream itself never waits, so
+            # the backward keeps running under the transfer and under the side stream's remaining kernels.
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            self.comm_stream.wait_event(ev)
+            if self.side_event[b] is not None:
+                self.comm_stream.wait_event(self.side_event[b])
+            with torch.cuda.stream(self.comm_stream):
+                h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.handles.append((h, view))
         self.launched[b] = True
 
-    def mark_ready(self, param_index: int):
+    def mark_ready(self, param_index: int, event=None):
+        """The gradient of parameter `param_index` has been enqueued; `event` (optional) = recorded behind its producer
+        when that ran on another stream than the current one."""
         b = self.bucket_of[param_index]
+        if event is not None:
+            self.side_event[b] = event
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
@@ -95,8 +123,25 @@ class BucketedGradSync:
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
+        timed = self.time_exposed and self.flat.is_cuda and self.world > 1
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h, view in self.handles:
             h.wait()
             if self.average and not self._use_avg and self.world > 1:
                 view.div_(self.world)
+        if self.flat.is_cuda and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed.append((e0, e1))      # no kernel sits between the two: their distance is the stall on the collectives
         self.reset()
+
+    def exposed_ms(self):
+        """Per-step time the launch stream spent waiting for the gradient all-reduce (needs time_exposed = True)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self.exposed]
+        self.exposed = []
+        return out

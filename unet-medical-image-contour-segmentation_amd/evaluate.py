@@ -12,15 +12,19 @@ from .utils.post_process import postprocess_mask
 
 
 @torch.inference_mode()
-def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=False):
+def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=True, process_group=None):
+    """evaluate.py:12-171.  `postprocess=True` is the reference's default (evaluate.py:13): the second return value is then
+    the Dice after post-processing and the minimum is taken over min(raw, post-processed) per batch (evaluate.py:85).
+    Batches are consumed lazily; under torch.distributed (every rank evaluating its shard of the validation set) the Dice
+    sums and batch counts are all-reduced so that every rank returns the metric of the whole set."""
     net.eval()
-    batches = list(dataloader)
-    num_val_batches = len(batches)
-    dice_score = 0
-    dice_post = 0
-    min_dice = 10
+    num_val_batches = 0
+    dice_score = torch.zeros((), dtype=torch.float32, device=device)
+    dice_post = torch.zeros((), dtype=torch.float32, device=device)
+    min_dice = torch.full((), 10.0, dtype=torch.float32, device=device)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-        for batch in batches:
+        for batch in dataloader:
+            num_val_batches += 1
             image, mask_true = batch["image"], batch["mask"]
             image = image.to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
             mask_true = mask_true.to(device=device, dtype=torch.float32)
@@ -48,10 +52,16 @@ def evaluate(net, dataloader, device, amp, epoch_pred_dir=None, postprocess=Fals
                     processed = postprocess_mask(idx.to(torch.uint8))                           # evaluate.py:125-134
                     dice_post += dice_coeff((processed == 2).float(), true_c, reduce_batch_first=False)
             dice_score += d
-            if cur < min_dice:
-                min_dice = cur
+            min_dice = torch.minimum(min_dice, cur.float())
     net.train()
-    n = max(num_val_batches, 1)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        acc = torch.stack([dice_score, dice_post, torch.tensor(float(num_val_batches), device=device)])
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=process_group)
+        dist.all_reduce(min_dice, op=dist.ReduceOp.MIN, group=process_group)
+        dice_score, dice_post, n = acc[0], acc[1], acc[2].clamp_min(1.0)
+    else:
+        n = max(num_val_batches, 1)
     if not postprocess:
         dice_post = dice_score                                                                  # evaluate.py:168-169
     return dice_score / n, dice_post / n, min_dice

@@ -386,6 +386,8 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
 # (process group, world size) when BatchNorm statistics are to be those of the GLOBAL batch of a data-parallel job
 # (TrainStepper(sync_bn=True)); None = per-rank statistics (what stock DDP does).
 SYNC_BN = None
+# (global batch, local batch) of the current step when SYNC_BN is on; None = equal shards
+SYNC_BN_BATCH = None
 
 
 def _sync_bn_forward(coef, m2, n_local, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps):
@@ -403,7 +405,10 @@ def _sync_bn_forward(coef, m2, n_local, Cout, g32, b32, running_mean, running_va
     stats = torch.empty(world * (2 * Cout + 2), dtype=torch.float32, device=dev)
     stats[:world * 2 * Cout].view(world, 2 * Cout).copy_(g2[:, :2 * Cout])
     stats[world * 2 * Cout:world * 2 * Cout + world].copy_(g2[:, 2 * Cout])
-    n_total = int(n_local) * world                      # equal shards (bench / DDP convention)
+    # the global pixel count: this rank's count scaled by global batch / local batch (TrainStepper all-reduces the batch
+    # sizes once per step, so ragged shards -- the last batch of an epoch -- get the right variance denominator)
+    gb, lb = SYNC_BN_BATCH if SYNC_BN_BATCH is not None else (world, 1)
+    n_total = int(n_local) * gb // lb
     scale, shift, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[3 * Cout:]
     LIB.call("uh_bn_finalize", stats.data_ptr(), world, Cout, n_total, g32.data_ptr(), b32.data_ptr(),
              _p(running_mean), _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(),
@@ -509,8 +514,9 @@ class ConvBnReluFn(Function):
                      shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
                      dbeta.data_ptr(), dy.data_ptr(), Cout, n, 0, Cout, dt, _stream())
         else:
-            # SyncBN: the parameter gradients stay LOCAL sums (the gradient all-reduce averages them like every other
-            # gradient); the dx formula needs the GLOBAL sums and the global pixel count
+            # SyncBN: the parameter gradients stay LOCAL sums (the gradient all-reduce SUMS them like every other
+            # gradient: the loss is already normalised by the global batch); the dx formula needs the GLOBAL sums and the
+            # global pixel count
             import torch.distributed as dist
             LIB.call("uh_bn_bwd_finalize", partials.data_ptr(), nblk, Cout, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
             glob = torch.cat([dgamma.reshape(-1), dbeta.reshape(-1)])
@@ -529,6 +535,7 @@ class ConvBnReluFn(Function):
             dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
         dweight = None
+        side_done = None
         if ctx.needs_input_grad[2]:
             dweight, cb_w = _grad_buffer(weight)
             if cb_w is not None and WGRAD_STREAM is not None and _is_krsc_dense(weight):
@@ -538,6 +545,8 @@ class ConvBnReluFn(Function):
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     conv3x3_wgrad(dy, x0, x1, dweight, ctx.cdt == UH_F32X3)
+                    side_done = torch.cuda.Event()
+                    side_done.record()              # the gradient all-reduce of this parameter's bucket waits for THIS
                 for t_ in (dy, x0, x1):
                     if t_ is not None:
                         t_.record_stream(side)      # the caching allocator must not recycle them under the side stream
@@ -549,7 +558,7 @@ class ConvBnReluFn(Function):
                 sO, sI, sH, sW = dweight.stride()
                 LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
             if cb_w is not None:
-                cb_w()
+                cb_w(side_done)
                 dweight = None
         if cb_g is not None:
             cb_g()

@@ -12,6 +12,7 @@ works unchanged: the modules are ordinary nn.Modules.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -75,34 +76,79 @@ class FusedRMSprop:
         self.ws = torch.empty(LIB.query("uh_optim_ws_bytes", off), dtype=torch.uint8, device=dev)
         self._index = {}
         self._grad_keys = []
+        self._hooks = []
+        self._closed = False
+        # one backward per step: which slices of flat_g hold THIS step's gradient (reset by zero_grad / step)
+        self._fresh = [False] * len(self.params)
         with torch.no_grad():
             for i, (p, (o, n)) in enumerate(zip(self.params, slices)):
                 if p.dtype != torch.float32:
                     raise RuntimeError("FusedRMSprop expects fp32 master parameters")
-                view = torch.as_strided(self.flat_p, p.shape, p.stride(), o)
                 if not _is_dense(p):
                     raise RuntimeError("parameters must be dense (contiguous or channels_last)")
+                # a parameter belongs to ONE FusedRMSprop: a stale owner's hook would steal the gradient (it fires first,
+                # copies p.grad into its dead buffer and clears it), so an earlier owner is closed here (take-over)
+                prev = getattr(p, "_uh_owner", None)
+                prev = prev() if prev is not None else None
+                if prev is not None and prev is not self:
+                    prev.close()
+                view = torch.as_strided(self.flat_p, p.shape, p.stride(), o)
                 view.copy_(p)
                 p.data = view
                 self._index[id(p)] = i
+                p._uh_owner = weakref.ref(self)
                 # backward kernels write this parameter's gradient straight into the flat buffer (ops.GRAD_DST)
                 ops.GRAD_DST[view.data_ptr()] = (torch.as_strided(self.flat_g, p.shape, p.stride(), o),
                                                  _weak_callback(self, i))
                 self._grad_keys.append(view.data_ptr())
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                # the hook holds the optimizer weakly (a bound method would keep it -- and its four flat buffers --
+                # alive for as long as the parameter lives) and its handle is kept so that close() can remove it
+                self._hooks.append(p.register_post_accumulate_grad_hook(_weak_grad_hook(self)))
         self.sync = None
         if dpmod.world_size(process_group) > 1:
             self.sync = dpmod.BucketedGradSync(self.flat_g, slices, bucket_bytes, process_group)
 
-    def __del__(self):
-        for k in getattr(self, "_grad_keys", []):
-            ops.GRAD_DST.pop(k, None)
+    def close(self):
+        """Detach from the parameters: hooks removed, in-place gradient destinations unregistered.  The parameters keep
+        their current values (they stay views of this optimizer's flat buffer until someone re-points them)."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for k in self._grad_keys:
+            ent = ops.GRAD_DST.get(k)
+            if ent is not None and ent[0].untyped_storage().data_ptr() == self.flat_g.untyped_storage().data_ptr():
+                ops.GRAD_DST.pop(k, None)
+        self._grad_keys = []
+        for p in self.params:
+            ref = getattr(p, "_uh_owner", None)
+            if ref is not None and ref() in (self, None):
+                p._uh_owner = None
 
-    def _written(self, i: int):
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mark(self, i: int, event=None):
+        if self._fresh[i]:
+            raise RuntimeError("FusedRMSprop: a second gradient for the same parameter arrived before step(): the backward "
+                               "kernels overwrite the flat gradient buffer, so gradient accumulation over several "
+                               "backward() calls is not supported (call zero_grad() + step() once per backward)")
+        self._fresh[i] = True
         if self.sync is not None:
-            self.sync.mark_ready(i)
+            self.sync.mark_ready(i, event)
+
+    def _written(self, i: int, event=None):
+        if not self._closed:
+            self._mark(i, event)
 
     def _on_grad(self, p: torch.Tensor):
+        if self._closed:
+            return
         i = self._index[id(p)]
         o, n = self.slices[i]
         g = p.grad
@@ -110,17 +156,40 @@ class FusedRMSprop:
             return
         torch.as_strided(self.flat_g, p.shape, p.stride(), o).copy_(g)     # parameters without an in-place writer
         p.grad = None
-        if self.sync is not None:
-            self.sync.mark_ready(i)
+        self._mark(i)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
+        self._fresh = [False] * len(self.params)
+
+    def abort_step(self):
+        """Drop the gradients of the current backward without applying them (NaN loss, train.py:149-151): the side
+        stream and any gradient all-reduce already in flight are drained so that the next step starts clean."""
+        if ops.WGRAD_STREAM is not None:
+            torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
+        if self.sync is not None:
+            self.sync.wait()
+        self._fresh = [False] * len(self.params)
 
     @torch.no_grad()
     def step(self):
+        if self._closed:
+            raise RuntimeError("FusedRMSprop.step() after close() (another FusedRMSprop took the parameters over)")
         if ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)     # weight gradients written on the side stream
+        # a parameter that received no gradient this step must not re-apply the previous step's (clipped) one: its
+        # slice is zeroed (torch.optim would skip the parameter; with zero gradient only weight decay / momentum act)
+        stale = [i for i, f in enumerate(self._fresh) if not f]
+        if stale and len(stale) < len(self._fresh):
+            for i in stale:
+                o, n = self.slices[i]
+                self.flat_g[o:o + n].zero_()
+                if self.sync is not None:
+                    self.sync.mark_ready(i)
+        elif stale:
+            raise RuntimeError("FusedRMSprop.step() without a backward pass since the last step / zero_grad")
+        self._fresh = [False] * len(self.params)
         if self.sync is not None:
             self.sync.wait()
         g = self.param_groups[0]
@@ -139,14 +208,23 @@ class FusedRMSprop:
         return torch.as_strided(self.flat_g, p.shape, p.stride(), o)
 
 
-def _weak_callback(opt: "FusedRMSprop", i: int):
-    import weakref
+def _weak_grad_hook(opt: "FusedRMSprop"):
     ref = weakref.ref(opt)
 
-    def cb():
+    def hook(p):
         o = ref()
         if o is not None:
-            o._written(i)
+            o._on_grad(p)
+    return hook
+
+
+def _weak_callback(opt: "FusedRMSprop", i: int):
+    ref = weakref.ref(opt)
+
+    def cb(event=None):
+        o = ref()
+        if o is not None:
+            o._written(i, event)
     return cb
 
 
@@ -191,7 +269,12 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
         # memory asynchronously and is read after backward has been ENQUEUED, still before the optimizer step: a NaN
         # loss raises the same error and never reaches the parameters.
         nan_host = torch.empty(1, dtype=torch.bool, pin_memory=True)
-        nan_host.copy_(torch.isnan(loss.detach()).reshape(1), non_blocking=True)
+        flag = torch.isnan(loss.detach()).reshape(1)
+        if reduce_sums is not None:
+            # data parallel: boundary_loss (and so the loss value) is per rank; every rank must take the SAME decision, or
+            # the ranks that continue hang at their next collective while one has raised
+            flag = reduce_sums(flag.float()) > 0
+        nan_host.copy_(flag, non_blocking=True)
         nan_event = torch.cuda.Event()
         nan_event.record()
     optimizer.zero_grad(set_to_none=True)
@@ -199,6 +282,8 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
     if nan_event is not None:
         nan_event.synchronize()
         if bool(nan_host.item()):
+            if isinstance(optimizer, FusedRMSprop):
+                optimizer.abort_step()
             raise RuntimeError("Fatal: NaN loss detected!")                                   # train.py:149-151
     if isinstance(optimizer, FusedRMSprop):
         terms["grad_norm"] = optimizer.step()
@@ -238,6 +323,10 @@ class TrainStepper:
     def step(self, images, true_masks):
         self.model.train()
         ops.SYNC_BN = self.sync_bn
+        ops.SYNC_BN_BATCH = None
+        if self.sync_bn is not None:
+            lb = int(images.shape[0])
+            ops.SYNC_BN_BATCH = (dpmod.global_batch(lb, self.group, images.device), lb)
         ops.FP32_MODE = self.fp32_mode
         # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
