@@ -108,9 +108,8 @@ def test_python_surface_uses_the_device_path():
 # ------------------------------------------------------------------------------------------------------------------
 def _oracle(masks, ed, ma):
     from oracle import cc_loss_ref as R
-    B = masks.shape[0]
-    # penalty_weight = B  ->  the function returns the plain penalty sum the C ABI reports in result[0]
-    return R.connected_component_loss(masks.astype(np.float32), edge_distance=ed, min_area=ma, penalty_weight=float(B))
+    # penalty_weight = 1  ->  (sum of penalties) / B, which is what the C ABI reports in result[0]
+    return R.connected_component_loss(masks.astype(np.float32), edge_distance=ed, min_area=ma, penalty_weight=1.0)
 
 
 @pytest.mark.parametrize("kind", ["noise", "sparse", "blobs"])
