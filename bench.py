@@ -99,10 +99,13 @@ def cpu_baseline(size: int):
                                         "timing only, the fixtures pin the fp32 leg"}}
 
 
-def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4):
+def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, hip_seeds=(0, 1, 2)):
     """BASELINE metric's second half, "Dice vs ref": the same `steps` train steps of UNet_T(1,1,bilinear) on seeded
     synthetic ellipse batches run by the CPU oracle (reference restatement) and by the HIP path (fp32 and bf16), then the
-    evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here)."""
+    evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here).
+    RMSprop's sign-like steps make the path to the plateau chaotic: last-bit differences move the Dice after 200 steps by
+    several points (scratch/dice_chaos2.py: 0.91-0.99 over 8 initialisations for one and the same binary), so the HIP
+    figures are means over `hip_seeds` initialisations (the first is the oracle's own initial state)."""
     import unet_amd
     from oracle import step_ref as S
     from oracle import unet_ref as U
@@ -120,15 +123,24 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
     out = {"model": f"UNet_T(1,1,bilinear) {batch}x1x{size}x{size}", "steps": steps, "lr": lr, "ref_cpu_fp32": round(float(d_ref), 4)}
     dev = torch.device("cuda", torch.cuda.current_device())
     for name, amp in (("hip_fp32", False), ("hip_bf16", True)):
-        model = unet_amd.UNet_T(1, 1, bilinear=True)
-        model.load_state_dict({k: v.clone() for k, v in init.items()})
-        model = model.to(dev)
-        stepper = unet_amd.TrainStepper(model, lr=lr, amp=amp)
-        for i in range(steps):
-            im, mk = train[i % len(train)]
-            stepper.step(im.to(dev), mk.to(dev))
-        d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp, postprocess=False)
-        out[name] = round(float(d), 4)
+        runs = []
+        for seed in hip_seeds:
+            model = unet_amd.UNet_T(1, 1, bilinear=True)
+            if seed == hip_seeds[0]:
+                model.load_state_dict({k: v.clone() for k, v in init.items()})
+            else:
+                sd = U.init_state(1, 1, True, widths=widths, seed=seed)
+                model.load_state_dict({k: v.clone() for k, v in sd.items()})
+            model = model.to(dev)
+            stepper = unet_amd.TrainStepper(model, lr=lr, amp=amp)
+            for i in range(steps):
+                im, mk = train[i % len(train)]
+                stepper.step(im.to(dev), mk.to(dev))
+            d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp, postprocess=False)
+            runs.append(round(float(d), 4))
+            stepper.optimizer.close()
+        out[name] = round(sum(runs) / len(runs), 4)
+        out[name + "_runs"] = runs
     return out
 
 

@@ -400,8 +400,10 @@ def test_dice_after_training_matches_oracle():
     r = bench.dice_vs_ref()
     _REPORT.append(f"dice_vs_ref {r}")
     assert r["ref_cpu_fp32"] > 0.9, r                      # the task is learned
-    assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.03, r
+    # HIP figures are means over three initialisations (the path to the plateau is chaotic: bench.dice_vs_ref)
+    assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.04, r
     assert abs(r["hip_bf16"] - r["ref_cpu_fp32"]) < 0.06, r
+    assert min(r["hip_fp32_runs"] + r["hip_bf16_runs"]) > 0.8, r
 
 
 def test_cc_loss_option_adds_value_only():

@@ -480,9 +480,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_BYTES];
-    // running (mean, M2) of this workgroup's channels over all the tiles it has finished: one BatchNorm partial row
-    // per WORKGROUP (<= 768 rows) instead of one per tile (8192 rows for a 512x512 batch of 8)
-    __shared__ float wg_mom[2][BN];
+    // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
+    // S1 = sum (v - p), S2 = sum (v - p)^2 with p = the channel's first stored value (so that |mean - p| ~ std and the
+    // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
+    __shared__ float wg_sum[3][BN];          // [0] = S1, [1] = S2, [2] = pivot; slot = channel - co_blk
     float n_run = 0.f;
 
     const int tid = threadIdx.x;
@@ -554,10 +555,26 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         }
     };
 
-    const T* wl = w + (int64_t)(co_w + lx) * 9 * Cin + kg * VEC;
-    const int64_t wnb_stride = (int64_t)16 * 9 * Cin;
+    // Which output channel an MFMA row holds.  The 16 rows of MFMA n land in the accumulator as 4 consecutive rows per lane
+    // group kg (acc[i][n][j] = row kg*4 + j, pixel lx).  The filter rows are handed to the MFMAs in a PERMUTED order so that
+    // what a lane holds for one pixel is one 16-byte piece of the NHWC output and the epilogue stores straight from the
+    // registers (no LDS bounce, no barrier):
+    //   bf16, NBW = 2:  row m of MFMA n = channel (m >> 2) * 8 + n * 4 + (m & 3): a lane's (n, j) values are 8 consecutive
+    //                   channels kg*8 .. kg*8+7 -> one 16-byte store per lane and pixel row, 64 contiguous bytes per pixel;
+    //   bf16, NBW = 1:  row m = channel cg(m >> 2) * 4 + (m & 3) with cg = {0, 2, 1, 3}: lanes l and l + 32 hold adjacent
+    //                   4-channel groups, so ONE v_permlane32_swap per dword pairs two pixel rows into 16-byte stores;
+    //   fp32:           the MFMA's own order (a lane's 4 channels of one MFMA are 16 bytes already).
+    constexpr bool PERM2 = (ES == 2 && NBW == 2), PERM1 = (ES == 2 && NBW == 1);
+    auto chan_of = [&](int grp, int n, int j) -> int {       // grp = row >> 2 (= kg for accumulators), j = row & 3
+        if constexpr (PERM2) return grp * 8 + n * 4 + j;
+        else if constexpr (PERM1) return ((((grp & 1) << 1) | (grp >> 1)) << 2) + j;
+        else return n * 16 + grp * 4 + j;
+    };
+    const int wrow0 = co_w + chan_of(lx >> 2, 0, lx & 3);
+    const T* wl = w + (int64_t)wrow0 * 9 * Cin + kg * VEC;
+    const int64_t wnb_stride = (int64_t)(PERM2 ? 4 : 16) * 9 * Cin;
     // SPLIT: `w` holds two bf16 arrays [Cout][9][Cin] (hi then lo); a fragment = 4 hi + 4 lo values in one u32x4
-    const bf16_t* wsh = reinterpret_cast<const bf16_t*>(w) + (int64_t)(co_w + lx) * 9 * Cin + kg * 4;
+    const bf16_t* wsh = reinterpret_cast<const bf16_t*>(w) + (int64_t)wrow0 * 9 * Cin + kg * 4;
     const int64_t wlo_off = (int64_t)Cout * 9 * Cin;
     auto wfrag = [&](int64_t off) -> u32x4 {             // off = n * wnb_stride + tap * Cin + chunk offset (elements)
         if constexpr (SPLIT) {
@@ -610,12 +627,14 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 
         for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
             const int c = chunk_of(v);
+#ifndef UH_ABL_NODMA          // timing-only ablation builds (scratch/ab_conv.py): results are wrong by construction
             if (v + 1 < nchunk) {
                 dma_chunk(pix_cur, chunk_of(v + 1), bufi ^ 1);
             } else if (next_tile < ntile) {
                 tile_pixels(next_tile, pix_cur);        // the current tile has no DMA left to issue
                 dma_chunk(pix_cur, 0, bufi ^ 1);
             }
+#endif
             const unsigned char* buf = lds + bufi * HALO2_BYTES;
             const int64_t wcp = (int64_t)c * CK;
             const int64_t wcp_next = (int64_t)((v + 1 < nchunk) ? chunk_of(v + 1) : 0) * CK;   // wraps to chunk 0 of the next tile
@@ -626,7 +645,13 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) wn[r][n] = wfrag(wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
+                    for (int n = 0; n < NBW; ++n) {
+#ifdef UH_ABL_NOW
+                        wn[r][n] = wc[r][n]; (void)wsrc;
+#else
+                        wn[r][n] = wfrag(wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
+#endif
+                    }
                 __builtin_amdgcn_sched_barrier(0);
                 // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
                 u32x4 xf[18];
@@ -676,8 +701,14 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             __syncthreads();     // the DMA issued above has landed (vmcnt(0) + barrier); this buffer is free again
         }
 
-        // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + n*16 + kg*4 + j]; this wave holds the
-        // whole tile for its channels, so the tile statistics need only 4 shuffles per value.
+#ifdef UH_ABL_NOEPI
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) asm volatile("" :: "v"(acc[i][n]));
+        continue;
+#endif
+        // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + chan_of(kg, n, j)]
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
         const int tyt = t % tilesY;
@@ -685,94 +716,149 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         const int y0 = tyt * TILE, x0p = txt * TILE;
         const int gx = x0p + lx;
         const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
-        const float inv_cnt = 1.f / (float)(vy * vx);
+        const bool full = (vy == TILE) && (vx == TILE);          // wave-uniform: interior tiles take the mask-free path
         if (ep_scale) {      // inference: eval-mode BatchNorm (per-channel scale/shift) + ReLU applied to the accumulators
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + co_w + n * 16 + kg * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + co_w + n * 16 + kg * 4);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + co_w + chan_of(kg, n, 0));
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + co_w + chan_of(kg, n, 0));
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][n][j] = uh_relu(fmaf(acc[i][n][j], sc[j], sh[j]));
             }
         }
-        float ssum[NBW][4];
+        // round to the stored type once: the statistics are those of the STORED values
 #pragma unroll
-        for (int n = 0; n < NBW; ++n)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ssum[n][j] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool ok = (y0 + i < H) && (gx < W);
+        for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
-                    ssum[n][j] += ok ? acc[i][n][j] : 0.f;
-                }
-        }
-        // Stores go through the LDS buffer this tile has just finished reading (the other one already holds the
-        // next tile's first chunk): the MFMA layout gives each lane 4 channels of one pixel (8-byte pieces strided
-        // by the pixel pitch); re-read as 16-byte pieces, a wave writes whole pixel rows = full 128-byte lines.
+                for (int j = 0; j < 4; ++j) acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
+
+        // ---- stores, straight from the registers
         {
-            constexpr int PITCH = BN * ES + 16;                       // +16 B: the 16 pixel lanes of a store spread over banks
-            constexpr int RP = (HALO2_BYTES / (TILE * PITCH)) >= 8 ? 8 : ((HALO2_BYTES / (TILE * PITCH)) >= 4 ? 4 : 2);
-            constexpr int PPR = BN * ES / 16;                         // 16-byte pieces per pixel
-            unsigned char* ob = lds + (bufi ^ 1) * HALO2_BYTES;
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += RP) {
-#pragma unroll
-                for (int i = 0; i < RP; ++i)
-#pragma unroll
-                    for (int n = 0; n < NBW; ++n) {
-                        unsigned char* dst = ob + (i * TILE + lx) * PITCH + (wave * (NBW * 16) + n * 16 + kg * 4) * ES;
-                        if constexpr (ES == 2) {
-                            bf16x4 o = {(bf16_t)acc[r0 + i][n][0], (bf16_t)acc[r0 + i][n][1], (bf16_t)acc[r0 + i][n][2],
-                                        (bf16_t)acc[r0 + i][n][3]};
-                            *reinterpret_cast<bf16x4*>(dst) = o;
-                        } else {
-                            *reinterpret_cast<f32x4*>(dst) = acc[r0 + i][n];
-                        }
-                    }
-                __syncthreads();
-                for (int p = tid; p < RP * TILE * PPR; p += 256) {
-                    const int px = p / PPR, part = p - px * PPR;
-                    const int gy = y0 + r0 + (px >> 4), gxx = x0p + (px & 15);
-                    if (gy < H && gxx < W && co_blk + part * VEC < Coutv) {
-                        u32x4 v = *reinterpret_cast<const u32x4*>(ob + px * PITCH + part * 16);
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y + (int64_t)((b * H + gy) * W + gxx) * ldy + co_blk) + part * 16) = v;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        if (stats) {
-#pragma unroll
-            for (int n = 0; n < NBW; ++n)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float mu = uh_row16_sum(ssum[n][j]) * inv_cnt;       // lanes of one kg = one DPP row
-                    float a = 0.f;
+            T* yrow = y + (int64_t)((b * H + y0) * W + gx) * ldy;          // pixel (row 0 of the tile, this lane's column)
+            const int64_t rstride = (int64_t)W * ldy;
+            if constexpr (PERM2) {
+                const int c0 = co_w + kg * 8;
+                if (gx < W && c0 < Coutv) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const bool ok = (y0 + i < H) && (gx < W);
-                        float d = acc[i][n][j] - mu;
-                        a += ok ? d * d : 0.f;
-                    }
-                    a = uh_row16_sum(a);
-                    if (lx == 0) {       // Chan merge of (count, mean, M2) into the workgroup's running moments; the
-                        const int cl = wave * (NBW * 16) + n * 16 + kg * 4 + j;      // same lane owns the slot every tile
-                        const float nb = (float)(vy * vx);
-                        if (n_run == 0.f) {
-                            wg_mom[0][cl] = mu;
-                            wg_mom[1][cl] = a;
-                        } else {
-                            const float ma = wg_mom[0][cl], tot = n_run + nb, d = mu - ma;
-                            wg_mom[0][cl] = ma + d * (nb / tot);
-                            wg_mom[1][cl] += a + d * d * (n_run * nb / tot);
+                        if (i < vy) {
+                            bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
+                                        (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
+                            *reinterpret_cast<bf16x8*>(yrow + i * rstride + c0) = o;
                         }
+                    }
+                }
+            } else if constexpr (PERM1) {
+                // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
+                const int c0 = co_w + (kg & 1) * 8;
+                const int rsel = kg >> 1;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    bf16x4 a = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3]};
+                    bf16x4 bq = {(bf16_t)acc[i + 1][0][0], (bf16_t)acc[i + 1][0][1], (bf16_t)acc[i + 1][0][2], (bf16_t)acc[i + 1][0][3]};
+                    u32x2 au = __builtin_bit_cast(u32x2, a), bu = __builtin_bit_cast(u32x2, bq);
+                    u32x4 o;
+                    {
+                        auto r0 = __builtin_amdgcn_permlane32_swap(au[0], bu[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(au[1], bu[1], false, false);
+                        o = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    }
+                    if (gx < W && c0 < Coutv && i + rsel < vy)
+                        *reinterpret_cast<u32x4*>(yrow + (i + rsel) * rstride + c0) = o;
+                }
+            } else {
+                if (gx < W) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (i < vy) {
+#pragma unroll
+                            for (int n = 0; n < NBW; ++n) {
+                                const int c0 = co_w + chan_of(kg, n, 0);
+                                if (c0 < Coutv) {
+                                    if constexpr (ES == 2) {
+                                        bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
+                                        *reinterpret_cast<bf16x4*>(yrow + i * rstride + c0) = o;
+                                    } else {
+                                        *reinterpret_cast<f32x4*>(yrow + i * rstride + c0) = acc[i][n];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- BatchNorm statistics: pivot-shifted sums per lane, 4 DPP adds per channel, accumulated in LDS by the lane that
+        // owns the channel's slot (the same lane every tile: no barrier, a wave only touches its own channels)
+        if (stats) {
+            float* S1 = &wg_sum[0][wave * (NBW * 16)];
+            float* S2 = &wg_sum[1][wave * (NBW * 16)];
+            float* PV = &wg_sum[2][wave * (NBW * 16)];
+            if (n_run == 0.f) {
+                // pivot = the tile's first stored value of each channel (pixel (0,0): lane lx == 0 of every lane group)
+                if (lx == 0) {
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int cl = chan_of(kg, n, j);
+                            PV[cl] = acc[0][n][j];
+                            S1[cl] = 0.f;
+                            S2[cl] = 0.f;
+                        }
+                }
+            }
+            float pv[NBW][4];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[chan_of(kg, n, 0)]);      // same-wave LDS write -> read: in order
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[n][j] = q[j];
+            }
+            float s1[NBW][4], s2[NBW][4];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[n][j] = 0.f; s2[n][j] = 0.f; }
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = acc[i][n][j] - pv[n][j];
+                            s1[n][j] += d;
+                            s2[n][j] = fmaf(d, d, s2[n][j]);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool ok = (i < vy) && (gx < W);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = ok ? acc[i][n][j] - pv[n][j] : 0.f;
+                            s1[n][j] += d;
+                            s2[n][j] = fmaf(d, d, s2[n][j]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a1 = uh_row16_sum(s1[n][j]), a2 = uh_row16_sum(s2[n][j]);   // lanes of one kg = one DPP row
+                    if (lx == 0) {
+                        const int cl = chan_of(kg, n, j);
+                        S1[cl] += a1;
+                        S2[cl] += a2;
                     }
                 }
             n_run += (float)(vy * vx);
@@ -782,13 +868,15 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         // row = tile lane of this workgroup; rows nlanes .. ntile-1 of the (per-tile sized) buffer get a zero pixel
         // count, which uh_bn_finalize skips
         if (lx == 0) {
+            const float inv_n = 1.f / n_run;
 #pragma unroll
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int cl = wave * (NBW * 16) + n * 16 + kg * 4 + j;
-                    stats[((int64_t)tile_lane * 2 + 0) * Cout + co_blk + cl] = wg_mom[0][cl];
-                    stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = wg_mom[1][cl];
+                    const int cl = wave * (NBW * 16) + chan_of(kg, n, j);
+                    const float a1 = wg_sum[0][cl], a2 = wg_sum[1][cl];
+                    stats[((int64_t)tile_lane * 2 + 0) * Cout + co_blk + cl] = wg_sum[2][cl] + a1 * inv_n;      // mean
+                    stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = fmaxf(a2 - a1 * a1 * inv_n, 0.f); // M2
                 }
         }
         float* counts = stats + (int64_t)ntile * 2 * Cout;
@@ -1787,7 +1875,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     __syncthreads();
     int bufi = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+#ifndef UH_ABL_WG_NODMA
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+#endif
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
         auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
@@ -1822,6 +1912,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         __syncthreads();    // drains the DMA of tile+1 (vmcnt(0)) and frees this buffer
     }
 
+#ifdef UH_ABL_WG_NOSTORE
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) asm volatile("" :: "v"(acc[tap]));
+    return;
+#endif
     float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
     const int ci = ci0 + wc * 32 + (lane & 31);
 #pragma unroll
