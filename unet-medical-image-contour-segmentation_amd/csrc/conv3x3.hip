@@ -448,7 +448,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
 //   * BatchNorm (mean, M2) per tile and channel come straight from the accumulator registers + 4 shuffles.
 // =====================================================================================
 constexpr int HALO2_BYTES = HALO_PIX * 64;   // 20736
+constexpr int HALO2_STRIDE = 6 * 4096;       // LDS bytes per halo buffer: six 4 KiB DMA rounds of 256 threads (the tail is padding)
 constexpr unsigned OOB_OFFSET = 0xF0000000u;
+
+// One LDS-DMA piece (buffer_load_dwordx4 ... lds: 16 bytes per lane, LDS address = M0 + 16 * lane) as inline asm: the
+// compiler does not see a memory operation, so it neither counts it in its own vmcnt bookkeeping nor drains it in front of
+// the next ds_read (which it does for the builtin: every LDS read after an LDS-DMA issue waits for that DMA).  The waits are
+// placed by hand (see the main loop).  desc = the four descriptor words in SGPRs.
+__device__ __forceinline__ void uh_dma16(u32x4 desc, unsigned lds_addr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
+}
+// 16-byte / 8-byte loads into registers, invisible to the compiler's wait insertion as well: the destination is valid only
+// after the hand-placed s_waitcnt that covers it.  "+v": the variable keeps its register across the loop.
+__device__ __forceinline__ void uh_ld16_async(u32x4& dst, u32x4 desc, unsigned voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void uh_ld8_async(u32x2& dst, u32x4 desc, unsigned voff, int soff) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 uh_desc_words(const void* p, unsigned bytes) {
+    const uint64_t a = (uint64_t)p;
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+#define UH_WAIT_VM(n) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // XOR applied to the 16-byte part index of a halo pixel in column hx: with part' = part ^ (2 * ((hx >> 2) & 1)) the 16 lanes of
 // every ds_read_b128 lane group (8 lanes of part k, 8 of part k^1, 16 consecutive pixels at ANY start) hit 16
@@ -463,7 +486,7 @@ template <typename T, int NBW, bool SPLIT = false>
 __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
-    int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes,
+    int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
     const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv) {
     // C0 / C1 / Cout are the channel counts the filter pack is laid out for (multiples of a chunk / of 64); C0v / C1v /
     // Coutv (<=) are the channels that exist in memory ("narrow" tensors of the small-width nets): input channels
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #endif
     constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_STRIDE];
     // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
     // S1 = sum (v - p), S2 = sum (v - p)^2 with p = the channel's first stored value (so that |mean - p| ~ std and the
     // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
@@ -515,44 +538,82 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     auto chunk_of = [&](int v) -> int { return v < nch0 ? v : v + skip1; };
     const int ntile = B * tilesX * tilesY;
 
-    // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q).
-    // One register per slot: (global pixel index << 2) | source part, or -1 for a pixel outside the image.
-    auto tile_pixels = [&](int tile, int (&pix)[NLOAD]) {
+    // ---- DMA bookkeeping: LDS slot p = tid + k*256 holds (halo pixel q = p >> 2, part' = p & 3) = source part part' ^ f(q).
+    // rel0[k] = byte offset of slot k's source piece from the halo tile's top-left pixel at pixel pitch ld0 -- a constant of
+    // the thread.  For a tile whose 18x18 halo lies inside the image (and a chunk whose 64 bytes exist in memory at pitch
+    // ld0: everything but the narrow tensors of the small nets) the address of a piece is rel0[k] + one wave-uniform base:
+    // ONE vector add per piece.  Tiles on the image border add the range tests; anything else takes the generic path.
+    const u32x4 rs0 = uh_desc_words(x0, x0_bytes);
+    const u32x4 rs1 = uh_desc_words(x1 ? x1 : x0, x1 ? x1_bytes : x0_bytes);
+    __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)y_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int rel0[NLOAD];
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+        const int p = tid + k * 256, q = p >> 2;
+        const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;          // q / 18 for q < 324
+        rel0[k] = (hy * W + hx) * ld0 * ES + (((p & 3) ^ halo_swz(hx)) << 4);
+    }
+    // tile the NEXT DMA reads from (scalars): image, top-left pixel, "halo inside the image"
+    int d_b = 0, d_y0 = 0, d_x0 = 0;
+    bool d_in = false;
+    auto dma_tile = [&](int tile) {
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
         const int tyt = t % tilesY;
-        const int b = t / tilesY;
-        const int y0 = tyt * TILE, x0p = txt * TILE;
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k) {
-            int p = tid + k * 256;
-            int q = p >> 2;
-            int hy = q / HALO_W, hx = q - hy * HALO_W;
-            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-            bool ok = (p < NPIECE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            pix[k] = ok ? ((((b * H + gy) * W + gx) << 2) | ((p & 3) ^ halo_swz(hx))) : -1;
-        }
+        d_b = t / tilesY;
+        d_y0 = tyt * TILE; d_x0 = txt * TILE;
+        d_in = d_y0 >= 1 && d_y0 + TILE + 1 <= H && d_x0 >= 1 && d_x0 + TILE + 1 <= W;
     };
-    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, (int)x0_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 ? x1 : x0), 0, (int)(x1 ? x1_bytes : x0_bytes), 0x00020000);
-
-    auto dma_chunk = [&](const int (&pix)[NLOAD], int c, int bufi) {
+    // EVERY thread issues exactly NLOAD pieces per call (the hand-placed vmcnt waits count instructions per wave): slots
+    // past the halo tile (and `live == false`: nothing left to fetch) read out of range, i.e. write zeros into the padding
+    // of the buffer / into a buffer nobody reads.
+    auto dma_chunk = [&](int c, int bufi, bool live) {
         const int cc = c * CK;
         const bool first = cc < C0;
         const int ld = first ? ld0 : ld1;
         const int soff = (first ? cc : cc - C0) * ES;
         const int cleft = first ? (C0v - cc) : (C1v - (cc - C0));      // channels of this chunk that exist in memory
-        typedef __attribute__((address_space(3))) void* lds_ptr;
-        unsigned char* dst = lds + bufi * HALO2_BYTES + wave * 1024;
+        const unsigned dst = lds_base + bufi * HALO2_STRIDE + wave * 1024;
+        const int base = ((d_b * H + d_y0 - 1) * W + d_x0 - 1) * ld0 * ES;     // may be negative: only used where in range
+        unsigned voff[NLOAD];
+        if (!live) {
 #pragma unroll
-        for (int k = 0; k < NLOAD; ++k) {
-            unsigned voff = (pix[k] >= 0 && (pix[k] & 3) * VEC < cleft) ? (unsigned)((pix[k] >> 2) * ld * ES + (pix[k] & 3) * 16)
-                                                                        : OOB_OFFSET;
-            if (k < NLOAD - 1 || tid + k * 256 < NPIECE) {
-                if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(dst + k * 4096), 16, voff, soff, 0, 0);
+            for (int k = 0; k < NLOAD; ++k) voff[k] = OOB_OFFSET;
+        } else if (ld == ld0 && cleft >= CK) {
+            if (d_in) {
+#pragma unroll
+                for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(rel0[k] + base);
+                if (tid + (NLOAD - 1) * 256 >= NPIECE) voff[NLOAD - 1] = OOB_OFFSET;
+            } else {
+                // (the opaque copy of tid keeps the per-slot coordinates from being hoisted out of the tile loop into 12
+                // long-lived registers: the main loop runs at the register limit)
+                int tid_o = tid;
+                asm volatile("" : "+v"(tid_o));
+#pragma unroll
+                for (int k = 0; k < NLOAD; ++k) {
+                    const int q = (tid_o + k * 256) >> 2;
+                    const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;
+                    const bool ok = (unsigned)(d_y0 - 1 + hy) < (unsigned)H && (unsigned)(d_x0 - 1 + hx) < (unsigned)W && q < HALO_PIX;
+                    voff[k] = ok ? (unsigned)(rel0[k] + base) : OOB_OFFSET;
+                }
+            }
+        } else {
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int p = tid_o + k * 256, q = p >> 2;
+                const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;
+                const int gy = d_y0 - 1 + hy, gx = d_x0 - 1 + hx;
+                const int part = (p & 3) ^ halo_swz(hx);
+                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && part * VEC < cleft && q < HALO_PIX;
+                voff[k] = ok ? (unsigned)(((d_b * H + gy) * W + gx) * ld * ES + part * 16) : OOB_OFFSET;
             }
         }
+        const u32x4 rs = first ? rs0 : rs1;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) uh_dma16(rs, dst + k * 4096, voff[k], soff);
     };
 
     // Which output channel an MFMA row holds.  The 16 rows of MFMA n land in the accumulator as 4 consecutive rows per lane
@@ -571,18 +632,22 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         else return n * 16 + grp * 4 + j;
     };
     const int wrow0 = co_w + chan_of(lx >> 2, 0, lx & 3);
-    const T* wl = w + (int64_t)wrow0 * 9 * Cin + kg * VEC;
     const int64_t wnb_stride = (int64_t)(PERM2 ? 4 : 16) * 9 * Cin;
-    // SPLIT: `w` holds two bf16 arrays [Cout][9][Cin] (hi then lo); a fragment = 4 hi + 4 lo values in one u32x4
-    const bf16_t* wsh = reinterpret_cast<const bf16_t*>(w) + (int64_t)wrow0 * 9 * Cin + kg * 4;
+    // Filter fragments come through a buffer descriptor: ONE per-lane byte offset (the lane's filter row and 16-byte part)
+    // plus a wave-uniform byte offset in an SGPR (chunk, tap, n) -- no 64-bit address arithmetic in vector registers -- as
+    // asynchronous loads whose waits are placed by hand (uh_ld16_async).
+    // SPLIT: `w` holds two bf16 arrays [Cout][9][Cin] (hi then lo); a fragment = 4 hi values + 4 lo values (two 8-byte loads).
     const int64_t wlo_off = (int64_t)Cout * 9 * Cin;
-    auto wfrag = [&](int64_t off) -> u32x4 {             // off = n * wnb_stride + tap * Cin + chunk offset (elements)
+    const u32x4 rsw = uh_desc_words(w, (unsigned)((int64_t)Cout * 9 * Cin * (SPLIT ? 4 : ES)));
+    const unsigned wvoff = (unsigned)(((int64_t)wrow0 * 9 * Cin + kg * (SPLIT ? 4 : VEC)) * (SPLIT ? 2 : ES));
+    struct WFrag { u32x4 v; u32x2 hi, lo; };     // non-SPLIT: v = the fragment; SPLIT: hi / lo = the bf16 halves of 4 values
+    constexpr int NWLOAD = 3 * NBW * (SPLIT ? 2 : 1);      // load instructions per column shift (one weight set)
+    auto wfrag_async = [&](WFrag& dst, int64_t off) {    // off = n * wnb_stride + tap * Cin + chunk offset (elements)
         if constexpr (SPLIT) {
-            const u32x2 h = *reinterpret_cast<const u32x2*>(wsh + off);
-            const u32x2 l = *reinterpret_cast<const u32x2*>(wsh + wlo_off + off);
-            return u32x4{h[0], h[1], l[0], l[1]};
+            uh_ld8_async(dst.hi, rsw, wvoff, (int)(off * 2));
+            uh_ld8_async(dst.lo, rsw, wvoff, (int)((off + wlo_off) * 2));
         } else {
-            return *reinterpret_cast<const u32x4*>(wl + off);
+            uh_ld16_async(dst.v, rsw, wvoff, (int)(off * ES));
         }
     };
     // fp32 pixel fragment (4 channels) -> {hi pair, hi pair, lo pair, lo pair} as bf16
@@ -601,104 +666,118 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         f = u32x4{hi[0], hi[1], lo[0], lo[1]};
     };
 
-    // Persistent over tiles: the DMA of the NEXT tile's first chunk is issued under the last chunk of the current
-    // tile, so a workgroup never waits for a cold HBM round trip after its first tile (matters for the
-    // HBM-bound 64-channel 512x512 layers, which have only 2 K-chunks per tile).
-    int pix_cur[NLOAD];
+    // Persistent over tiles.  Every vector-memory operation of the main loop (halo DMA, filter fragments) is issued through
+    // inline asm and waited for by hand-counted s_waitcnt: vmcnt retires IN ORDER, so what matters is the ORDER of issue.
+    // Per chunk (W* = the NWLOAD fragment loads of one column shift, D = the 6 DMA pieces of the NEXT chunk's halo tile):
+    //     issue WB                         | shift 0 (fragments WA, waited for at the end of the previous chunk)
+    //     issue WC, D ; wait vmcnt(NWLOAD+6) -> WB landed        | shift 1
+    //     issue WA'   ; wait vmcnt(6+NWLOAD) -> WC landed        | shift 2   (D and WA' stay in flight)
+    //     wait vmcnt(0), lgkmcnt(0) ; s_barrier                  -> D and WA' landed, the buffer just read is free
+    // The DMA has two column shifts of MFMAs (2 x 48 x NBW) to land under; the compiler sees no memory operation in the loop
+    // except the LDS fragment reads, so it inserts no wait of its own (for the LDS-DMA builtin it drains the DMA in front of
+    // every following ds_read).  The epilogue's stores are ordinary buffer stores issued BEFORE the statistics: the first
+    // wait that covers them is the WB wait of the next tile's first chunk, one column shift + the statistics later.
     int tile = tile_lane;
     if (tile >= ntile) return;
-    tile_pixels(tile, pix_cur);
-    dma_chunk(pix_cur, 0, 0);
-    u32x4 wc[3][NBW], wn[3][NBW];
+    WFrag wA[3][NBW], wB[3][NBW], wC[3][NBW];      // filter fragments of column shift 0 / 1 / 2
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int n = 0; n < NBW; ++n) wc[r][n] = wfrag(n * wnb_stride + (int64_t)(r * 3) * Cin);
-    __syncthreads();     // drains the DMA (vmcnt(0)) before anyone reads buffer 0
+        for (int n = 0; n < NBW; ++n) {
+            wA[r][n].v = wB[r][n].v = wC[r][n].v = u32x4{0u, 0u, 0u, 0u};
+            wA[r][n].hi = wB[r][n].hi = wC[r][n].hi = wA[r][n].lo = wB[r][n].lo = wC[r][n].lo = u32x2{0u, 0u};
+        }
+    auto load_w = [&](WFrag (&dst)[3][NBW], int64_t wsrc) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) wfrag_async(dst[r][n], wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
+    };
     int bufi = 0;
+    // one column shift: rolling window over the 18 halo rows, row k+1 is fetched from LDS while output row k-2 is multiplied
+    f32x4 acc[16][NBW];
+    auto mma_shift = [&](const unsigned char* buf, int sft, WFrag (&wv)[3][NBW]) {
+        u32x4 xf[18];
+        // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
+        const unsigned char* xcol = buf + (lx + sft) * 64 + ((kg ^ halo_swz(lx + sft)) << 4);
+        auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
+#pragma unroll
+        for (int k = 0; k < 2 + PF; ++k) xf[k] = rd(k);
+#pragma unroll
+        for (int k = 2; k < 18; ++k) {
+            if (k + PF < 18) xf[k + PF] = rd(k + PF);     // PF rows ahead of the row being multiplied
+            __builtin_amdgcn_sched_barrier(0);            // the read stays above this row's MFMAs
+            if constexpr (SPLIT) {                        // row k's fragment is first used now: split it once
+                if (k == 2) { split4(xf[0]); split4(xf[1]); }
+                split4(xf[k]);
+            }
+            const int i = k - 2;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    if constexpr (ES == 2) {
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wv[r][n].v), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                    } else if constexpr (SPLIT) {
+                        const s16x4 wh = __builtin_bit_cast(s16x4, wv[r][n].hi);
+                        const s16x4 wlo = __builtin_bit_cast(s16x4, wv[r][n].lo);
+                        const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{xf[i + r][0], xf[i + r][1]});
+                        const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xf[i + r][2], xf[i + r][3]});
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xlo, acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[i][n], 0, 0, 0);
+                    } else {
+                        f32x4 a = __builtin_bit_cast(f32x4, wv[r][n].v);
+                        f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    dma_tile(tile);
+    dma_chunk(chunk_of(0), 0, true);
+    load_w(wA, (int64_t)chunk_of(0) * CK);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 
     for (; tile < ntile; tile += nlanes) {
         const int next_tile = tile + nlanes;
-        f32x4 acc[16][NBW];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
-            const int c = chunk_of(v);
-#ifndef UH_ABL_NODMA          // timing-only ablation builds (scratch/ab_conv.py): results are wrong by construction
-            if (v + 1 < nchunk) {
-                dma_chunk(pix_cur, chunk_of(v + 1), bufi ^ 1);
-            } else if (next_tile < ntile) {
-                tile_pixels(next_tile, pix_cur);        // the current tile has no DMA left to issue
-                dma_chunk(pix_cur, 0, bufi ^ 1);
-            }
-#endif
-            const unsigned char* buf = lds + bufi * HALO2_BYTES;
-            const int64_t wcp = (int64_t)c * CK;
-            const int64_t wcp_next = (int64_t)((v + 1 < nchunk) ? chunk_of(v + 1) : 0) * CK;   // wraps to chunk 0 of the next tile
 #pragma unroll 1
-            for (int s = 0; s < 3; ++s) {
-                // prefetch the filter fragments of the next column shift (or of the next chunk's first one)
-                const int64_t wsrc = (s < 2) ? (wcp + (int64_t)(s + 1) * Cin) : wcp_next;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int n = 0; n < NBW; ++n) {
-#ifdef UH_ABL_NOW
-                        wn[r][n] = wc[r][n]; (void)wsrc;
-#else
-                        wn[r][n] = wfrag(wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
-#endif
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                // rolling window over the 18 halo rows: row k+1 is fetched from LDS while output row k-2 is multiplied
-                u32x4 xf[18];
-                // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
-                const unsigned char* xcol = buf + (lx + s) * 64 + ((kg ^ halo_swz(lx + s)) << 4);
-                auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
-#pragma unroll
-                for (int k = 0; k < 2 + PF; ++k) xf[k] = rd(k);
-#pragma unroll
-                for (int k = 2; k < 18; ++k) {
-                    if (k + PF < 18) xf[k + PF] = rd(k + PF);     // PF rows ahead of the row being multiplied
-                    __builtin_amdgcn_sched_barrier(0);      // the read stays above this row's MFMAs
-                    if constexpr (SPLIT) {                  // row k's fragment is first used now: split it once
-                        if (k == 2) { split4(xf[0]); split4(xf[1]); }
-                        split4(xf[k]);
-                    }
-                    const int i = k - 2;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int n = 0; n < NBW; ++n) {
-                            if constexpr (ES == 2) {
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, wc[r][n]), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
-                            } else if constexpr (SPLIT) {
-                                const s16x4 wh = __builtin_bit_cast(s16x4, u32x2{wc[r][n][0], wc[r][n][1]});
-                                const s16x4 wlo = __builtin_bit_cast(s16x4, u32x2{wc[r][n][2], wc[r][n][3]});
-                                const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{xf[i + r][0], xf[i + r][1]});
-                                const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xf[i + r][2], xf[i + r][3]});
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[i][n], 0, 0, 0);
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xlo, acc[i][n], 0, 0, 0);
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[i][n], 0, 0, 0);
-                            } else {
-                                f32x4 a = __builtin_bit_cast(f32x4, wc[r][n]);
-                                f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
-#pragma unroll
-                                for (int qq = 0; qq < 4; ++qq)
-                                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq], bb[qq], acc[i][n], 0, 0, 0);
-                            }
-                        }
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int n = 0; n < NBW; ++n) wc[r][n] = wn[r][n];
+        for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
+            const int64_t wcp = (int64_t)chunk_of(v) * CK;
+            const int64_t wcp_next = (int64_t)chunk_of((v + 1 < nchunk) ? v + 1 : 0) * CK;   // wraps to chunk 0 of the next tile
+            const unsigned char* buf = lds + bufi * HALO2_STRIDE;
+            load_w(wB, wcp + (int64_t)Cin);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_shift(buf, 0, wA);
+            load_w(wC, wcp + 2 * (int64_t)Cin);
+            // the halo tile of what follows chunk v: the tile's next chunk, else chunk 0 of the workgroup's next tile, else
+            // nothing (six out-of-range pieces keep the instruction count of the waits below)
+            if (v + 1 < nchunk) {
+                dma_chunk(chunk_of(v + 1), bufi ^ 1, true);
+            } else {
+                const bool more = next_tile < ntile;
+                if (more) dma_tile(next_tile);
+                dma_chunk(chunk_of(0), bufi ^ 1, more);
             }
-            __syncthreads();     // the DMA issued above has landed (vmcnt(0) + barrier); this buffer is free again
+            UH_WAIT_VM(NWLOAD + NLOAD);               // WB landed (WC and the DMA stay in flight)
+            mma_shift(buf, 1, wB);
+            load_w(wA, wcp_next);
+            UH_WAIT_VM(NLOAD + NWLOAD);               // WC landed (the DMA and WA' stay in flight)
+            mma_shift(buf, 2, wC);
+            // DMA and WA' landed; every wave has finished reading this buffer
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
 
 #ifdef UH_ABL_NOEPI
@@ -736,56 +815,60 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
 
-        // ---- stores, straight from the registers
+        // ---- stores, straight from the registers through a buffer descriptor: per-lane byte offset (column, channel
+        // piece; out of range for columns / channels that do not exist, which drops the store) + the row offset.  The row
+        // offset is ADDED to the vector offset instead of riding in the scalar-offset operand: a 16-byte buffer store with a
+        // scalar offset register reads its data over several cycles, and hipcc (ROCm 7.2) let the next VALU instruction
+        // overwrite the first data register behind the last store of the loop (wrong bf16 pairs in 8 lanes of one row pair).
         {
-            T* yrow = y + (int64_t)((b * H + y0) * W + gx) * ldy;          // pixel (row 0 of the tile, this lane's column)
-            const int64_t rstride = (int64_t)W * ldy;
+            const int rbytes = W * ldy * ES;                                   // one image row of y
+            const int sbase = ((b * H + y0) * W) * ldy * ES;                   // row 0 of the tile, column 0
             if constexpr (PERM2) {
                 const int c0 = co_w + kg * 8;
-                if (gx < W && c0 < Coutv) {
+                const bool inr = gx < W && c0 < Coutv;
+                const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        if (i < vy) {
-                            bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
-                                        (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
-                            *reinterpret_cast<bf16x8*>(yrow + i * rstride + c0) = o;
-                        }
+                for (int i = 0; i < 16; ++i) {
+                    if (i < vy) {
+                        bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
+                                    (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, inr ? voff + (unsigned)(sbase + i * rbytes) : OOB_OFFSET, 0, 0);
                     }
                 }
             } else if constexpr (PERM1) {
                 // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
                 const int c0 = co_w + (kg & 1) * 8;
                 const int rsel = kg >> 1;
+                const bool inr = gx < W && c0 < Coutv;
+                const unsigned voff0 = (unsigned)((gx * ldy + c0) * ES + rsel * rbytes);
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     bf16x4 a = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3]};
                     bf16x4 bq = {(bf16_t)acc[i + 1][0][0], (bf16_t)acc[i + 1][0][1], (bf16_t)acc[i + 1][0][2], (bf16_t)acc[i + 1][0][3]};
                     u32x2 au = __builtin_bit_cast(u32x2, a), bu = __builtin_bit_cast(u32x2, bq);
-                    u32x4 o;
-                    {
-                        auto r0 = __builtin_amdgcn_permlane32_swap(au[0], bu[0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(au[1], bu[1], false, false);
-                        o = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    auto r0 = __builtin_amdgcn_permlane32_swap(au[0], bu[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(au[1], bu[1], false, false);
+                    const u32x4 o = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    if (i < vy) {          // (vy odd: the row i+1 half of the last pair is dropped per lane)
+                        const unsigned voff = (inr && i + rsel < vy) ? voff0 + (unsigned)(sbase + i * rbytes) : OOB_OFFSET;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsy, voff, 0, 0);
                     }
-                    if (gx < W && c0 < Coutv && i + rsel < vy)
-                        *reinterpret_cast<u32x4*>(yrow + (i + rsel) * rstride + c0) = o;
                 }
             } else {
-                if (gx < W) {
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    const int c0 = co_w + chan_of(kg, n, 0);
+                    const bool inr = gx < W && c0 < Coutv;
+                    const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         if (i < vy) {
-#pragma unroll
-                            for (int n = 0; n < NBW; ++n) {
-                                const int c0 = co_w + chan_of(kg, n, 0);
-                                if (c0 < Coutv) {
-                                    if constexpr (ES == 2) {
-                                        bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
-                                        *reinterpret_cast<bf16x4*>(yrow + i * rstride + c0) = o;
-                                    } else {
-                                        *reinterpret_cast<f32x4*>(yrow + i * rstride + c0) = acc[i][n];
-                                    }
-                                }
+                            const unsigned vo = inr ? voff + (unsigned)(sbase + i * rbytes) : OOB_OFFSET;
+                            if constexpr (ES == 2) {
+                                bf16x4 o = {(bf16_t)acc[i][n][0], (bf16_t)acc[i][n][1], (bf16_t)acc[i][n][2], (bf16_t)acc[i][n][3]};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsy, vo, 0, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][n]), rsy, vo, 0, 0);
                             }
                         }
                     }
@@ -813,54 +896,37 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                         }
                 }
             }
-            float pv[NBW][4];
+            // one channel at a time (3 live temporaries instead of 3 per channel: the epilogue runs at the register limit)
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[chan_of(kg, n, 0)]);      // same-wave LDS write -> read: in order
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[n][j] = q[j];
-            }
-            float s1[NBW][4], s2[NBW][4];
-#pragma unroll
-            for (int n = 0; n < NBW; ++n)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[n][j] = 0.f; s2[n][j] = 0.f; }
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-#pragma unroll
-                    for (int n = 0; n < NBW; ++n)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float d = acc[i][n][j] - pv[n][j];
-                            s1[n][j] += d;
-                            s2[n][j] = fmaf(d, d, s2[n][j]);
-                        }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool ok = (i < vy) && (gx < W);
-#pragma unroll
-                    for (int n = 0; n < NBW; ++n)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float d = ok ? acc[i][n][j] - pv[n][j] : 0.f;
-                            s1[n][j] += d;
-                            s2[n][j] = fmaf(d, d, s2[n][j]);
-                        }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NBW; ++n)
-#pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a1 = uh_row16_sum(s1[n][j]), a2 = uh_row16_sum(s2[n][j]);   // lanes of one kg = one DPP row
+                    const float pv = q[j];
+                    float s1 = 0.f, s2 = 0.f;
+                    if (full) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float d = acc[i][n][j] - pv;
+                            s1 += d;
+                            s2 = fmaf(d, d, s2);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float d = ((i < vy) && (gx < W)) ? acc[i][n][j] - pv : 0.f;
+                            s1 += d;
+                            s2 = fmaf(d, d, s2);
+                        }
+                    }
+                    const float a1 = uh_row16_sum(s1), a2 = uh_row16_sum(s2);   // lanes of one kg = one DPP row
                     if (lx == 0) {
                         const int cl = chan_of(kg, n, j);
                         S1[cl] += a1;
                         S2[cl] += a2;
                     }
                 }
+            }
             n_run += (float)(vy * vx);
         }
     }
@@ -1324,7 +1390,9 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                          ((ld0 * ES) % 16 == 0) && (C1 == 0 || (ld1 * ES) % 16 == 0) && ((ldy * ES) % 16 == 0);
     if (mfma_ok) {
         const int64_t b0 = (int64_t)B * H * W * ld0 * ES, b1 = C1 ? (int64_t)B * H * W * ld1 * ES : 0;
-        if (b0 < (1ll << 31) - 4096 && b1 < (1ll << 31) - 4096) {
+        // y and the filter pack are addressed through buffer descriptors as well (32-bit offsets)
+        const int64_t by = (int64_t)B * H * W * ldy * ES, bw = (int64_t)Cout * 9 * Cin * (split ? 4 : ES);
+        if (b0 < (1ll << 31) - 4096 && b1 < (1ll << 31) - 4096 && by < (1ll << 31) - 4096 && bw < (1ll << 31) - 4096) {
             // 128-channel slabs halve the halo re-reads, but small feature maps need the extra workgroups
             // persistent workgroups: 2 (NBW=2, VGPR-bound) or 3 (NBW=1) per CU, spread over the channel slabs; the
             // number of tile lanes is rounded to a multiple of 8 for the XCD-aware mapping inside the kernel
@@ -1342,19 +1410,19 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
             *ep_done = ep_scale != nullptr;
