@@ -36,7 +36,16 @@ enum { UH_F32 = 0, UH_BF16 = 1,
         * Cout*9*Cin elements each into the same number of bytes as the fp32 pack), uh_conv3x3_fwd,
         * uh_conv3x3_fwd_affine_relu (MFMA-aligned shapes only: Cin % 16 == 0, Cout % 64 == 0) and uh_conv3x3_wgrad
         * (channel counts multiples of 64). */
-       UH_F32X3 = 2 };
+       UH_F32X3 = 2,
+       /* Flags OR-ed into the dtype argument of uh_pack_w3x3 and uh_conv3x3_fwd / uh_conv3x3_fwd_affine_relu: the packed
+        * filter is FRAGMENT-MAJOR instead of KRSC -- 1 KiB blocks, one per (16 filter rows, tap, 64-byte K chunk), laid out
+        * as the 64 lanes of an MFMA A-operand read them, so that the conv kernel's fragment load is 8 whole cache lines
+        * instead of 16 half lines (the forward kernel was bound by its vector-memory path, not by the matrix pipe).  Only
+        * for calls that uh_conv3x3_wfrag_ok() accepts (the LDS-DMA MFMA kernel); UH_WFRAG = forward copy / the `w` of a
+        * conv call, UH_WFRAG_D = backward-data copy of uh_pack_w3x3 (it is the `w` of the backward-data conv call, which
+        * then passes UH_WFRAG).  In uh_pack_w3x3_batched the flags are per layer (table column 9: bit 0 forward copy,
+        * bit 1 backward-data copy). */
+       UH_WFRAG = 0x100, UH_WFRAG_D = 0x200 };
 enum { UH_OK = 0, UH_EINVAL = -1, UH_ELAUNCH = -2, UH_EWORKSPACE = -3 };
 
 const char* uh_last_error(void);
@@ -49,8 +58,9 @@ int uh_version(void);
 int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
                  void* w_fwd, void* w_dgrad, int dt, uh_stream stream);
 /* All layers at once: table = nlayers x 10 int64 on the DEVICE {w pointer, sO, sI, sH, sW, Cout, Cin, first element
- * of the layer in the flat outputs, first tile of the layer, 0}; a layer has ceil(Cout/32)*ceil(Cin/32)*9 tiles and
- * ntiles is their sum.  w_dgrad_flat may be NULL. */
+ * of the layer in the flat outputs, first tile of the layer, flags}; a layer has ceil(Cout/32)*ceil(Cin/32)*9 tiles and
+ * ntiles is their sum.  flags: bit 0 / bit 1 = forward / backward-data copy fragment-major (UH_WFRAG).  w_dgrad_flat may
+ * be NULL. */
 int uh_pack_w3x3_batched(const int64_t* table, int nlayers, int64_t ntiles, void* w_fwd_flat,
                          void* w_dgrad_flat, int dt, uh_stream stream);
 /* KRSC fp32 weight gradient -> gradient tensor with the parameter's own strides. */
@@ -67,6 +77,9 @@ int uh_unpack_dw3x3(const float* dw_krsc, float* dw, int64_t sO, int64_t sI, int
  * statistics (unet_parts.py:16,19) without a second pass over y.  With w = w_dgrad this is conv
  * backward-data. */
 int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int dt);
+/* 1 if uh_conv3x3_fwd will run this shape on the LDS-DMA MFMA kernel (16-byte aligned pointers assumed), i.e. if the
+ * filter may be packed fragment-major (UH_WFRAG); dt = UH_F32 or UH_BF16. */
+int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout, int ld0, int ld1, int ldy, int dt);
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
                    int B, int H, int W, int dt, uh_stream stream);

@@ -33,6 +33,8 @@ class Lib:
     def __init__(self, path):
         self.dll = ctypes.CDLL(path)
         for name, (ret, types) in L.parse_header().items():
+            if not hasattr(self.dll, name):       # an older build of the ABI (A/B baselines)
+                continue
             fn = getattr(self.dll, name)
             fn.restype = L._RET[ret]
             fn.argtypes = [ctypes.c_void_p if t == "ptr" else L._CTYPES[t] for t in types]
@@ -53,6 +55,7 @@ def main():
     ap.add_argument("--shapes", default="down2")
     ap.add_argument("--kernels", default="fwd_conv1,fwd_conv2,dgrad_conv2,dgrad_conv1,wgrad_conv2,wgrad_conv1")
     ap.add_argument("--json", default="")
+    ap.add_argument("--krsc", action="store_true", help="KRSC filter packs for every library (no fragment-major packs)")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     libs = [(a.split("=")[0], Lib(a.split("=")[1])) for a in args.libs]
@@ -71,15 +74,20 @@ def main():
         w2 = (torch.randn(Cout, Cout, 3, 3, generator=g) / (3 * Cout ** 0.5)).to(dev)
         base = libs[0][1]
 
-        def pack(w):
+        def pack(lb, w, flags=0):
             O, I = w.shape[0], w.shape[1]
             wf = torch.empty(O * 9 * I, dtype=torch.bfloat16, device=dev)
             wd = torch.empty(O * 9 * I, dtype=torch.bfloat16, device=dev)
             sO, sI, sH, sW = w.stride()
-            base.call("uh_pack_w3x3", w.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), wd.data_ptr(), dt, st)
+            lb.call("uh_pack_w3x3", w.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), wd.data_ptr(), dt | flags, st)
             return wf, wd
-        w1f, w1d = pack(w1)
-        w2f, w2d = pack(w2)
+        w1f, w1d = pack(base, w1)
+        w2f, w2d = pack(base, w2)
+        # fragment-major packs (UH_WFRAG = 0x100 forward copy, 0x200 backward-data copy) for the libraries that know them
+        fragp = {}
+        for ln, lb in libs:
+            if hasattr(lb.dll, "uh_conv3x3_wfrag_ok") and not args.krsc:
+                fragp[ln] = (pack(lb, w1, 0x300), pack(lb, w2, 0x300))
         yo = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
         xo = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
         nslab = base.query("uh_conv3x3_stat_slabs", B, H, W, Cin, Cout, dt)
@@ -91,9 +99,16 @@ def main():
             wsb = max(wsb, lb.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cout, Cout, dt), lb.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout, dt))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
+        cur = {"name": None}
+
         def fwd(lb, src, cin, wp, dst, cout, stat):
+            flag = 0
+            fp = fragp.get(cur["name"])
+            if fp is not None:          # swap the KRSC pack for this library's fragment-major copy of the same filter
+                wp = {id(w1f): fp[0][0], id(w1d): fp[0][1], id(w2f): fp[1][0], id(w2d): fp[1][1]}[id(wp)]
+                flag = 0x100
             lb.call("uh_conv3x3_fwd", src.data_ptr(), cin, cin, None, 0, 0, wp.data_ptr(), dst.data_ptr(), cout, cout,
-                    None if stat is None else stat.data_ptr(), B, H, W, dt, st)
+                    None if stat is None else stat.data_ptr(), B, H, W, dt | flag, st)
 
         def wgrad(lb, dy, src, cin):
             lb.call("uh_conv3x3_wgrad", dy.data_ptr(), Cout, src.data_ptr(), cin, cin, None, 0, 0, dw.data_ptr(), Cout,
@@ -113,18 +128,21 @@ def main():
         times = {(ln, k): [] for ln, _ in libs for k in kernels}
         diffs = {}
         # correctness vs variant 0
+        def run(ln, lb, fn):
+            cur["name"] = ln
+            fn(lb)
         for k, (fn, _, out) in kernels.items():
-            fn(libs[0][1]); torch.cuda.synchronize()
+            run(libs[0][0], libs[0][1], fn); torch.cuda.synchronize()
             ref = out().float().clone()
             for ln, lb in libs[1:]:
                 out().zero_()
-                fn(lb); torch.cuda.synchronize()
+                run(ln, lb, fn); torch.cuda.synchronize()
                 diffs[(ln, k)] = float((out().float() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
         # warm the clocks
         for _ in range(3):
             for ln, lb in libs:
                 for k, (fn, _, _) in kernels.items():
-                    fn(lb)
+                    run(ln, lb, fn)
         torch.cuda.synchronize()
         for r in range(args.rounds):
             order = libs if r % 2 == 0 else libs[::-1]
@@ -133,7 +151,7 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(args.iters):
-                        fn(lb)
+                        run(ln, lb, fn)
                     e1.record()
                     torch.cuda.synchronize()
                     times[(ln, k)].append(e0.elapsed_time(e1) / args.iters)

@@ -78,6 +78,24 @@ def _conv_case(dtype, B, H, W, C0, C1, Cout):
     wf, wdg = ops.pack_w3x3(w.to(dev), dtype, True)
     y, stats, nslab = ops.conv3x3_fwd(x0, x1, wf, Cout, True)
     tol = 2e-5 if dtype == torch.float32 else 1e-2
+    # fragment-major filter packs (UH_WFRAG), wherever the LDS-DMA MFMA kernel takes the call: bit-identical results
+    dtc = ops._dt(xg)
+    ok_f = ops.wfrag_ok(B, H, W, C0, C1, Cout, ops.pixel_ld(x0), 0 if x1 is None else ops.pixel_ld(x1), Cout, dtc)
+    ok_d = ops.wfrag_ok(B, H, W, Cout, 0, Cin, Cout, 0, Cin, dtc)
+    if ok_f or ok_d:
+        wf2, wd2 = ops.pack_w3x3(w.to(dev), dtype, True, None, ok_f, ok_d)
+        if ok_f:
+            y2, st2, _ = ops.conv3x3_fwd(x0, x1, wf2, Cout, True, None, True)
+            assert torch.equal(y2, y)
+            c1, c2 = stats[nslab * 2 * Cout:nslab * 2 * Cout + nslab], st2[nslab * 2 * Cout:nslab * 2 * Cout + nslab]
+            assert torch.equal(c1, c2)                  # pixel counts; rows with a zero count hold nothing
+            live = c1 > 0
+            assert torch.equal(st2[:nslab * 2 * Cout].view(nslab, 2 * Cout)[live], stats[:nslab * 2 * Cout].view(nslab, 2 * Cout)[live])
+        if ok_d:
+            dyg_ = _nhwc(dy, dtype, dev)
+            dxa, _, _ = ops.conv3x3_fwd(dyg_, None, wdg, Cin, False)
+            dxb, _, _ = ops.conv3x3_fwd(dyg_, None, wd2, Cin, False, None, True)
+            assert torch.equal(dxa, dxb)
 
     def rel(a, b):
         return float((a.double().cpu() - b).abs().max() / b.abs().max())
@@ -354,20 +372,30 @@ def test_batched_weight_pack_matches_per_layer(dtype):
         ws.append(w)
     pack = ops.ConvWeightPack(ws, dtype)
     pack.refresh()
-    for w in ws:
-        hit = pack.lookup(w, dtype)
+    nfrag = 0
+    for w, fr in zip(ws, pack.frags):
+        # every layer is packed in the layouts the pack chose (fragment-major where the MFMA kernel will consume it);
+        # asking for another layout is a miss
+        hit = pack.lookup(w, dtype, *fr)
         assert hit is not None
-        wf, wd = ops.pack_w3x3(w, dtype, True)
+        wf, wd = ops.pack_w3x3(w, dtype, True, None, *fr)
         assert torch.equal(hit[0], wf) and torch.equal(hit[1], wd)
-    assert pack.lookup(ws[0], torch.float32 if dtype == torch.bfloat16 else torch.bfloat16) is None
+        assert pack.lookup(w, dtype, not fr[0], fr[1]) is None
+        nfrag += int(fr[0]) + int(fr[1])
+        if fr[0]:                 # a fragment-major pack is a permutation of the KRSC pack
+            kr = ops.pack_w3x3(w, dtype, False)[0]
+            assert torch.equal(torch.sort(wf.float())[0], torch.sort(kr.float())[0]) and not torch.equal(wf, kr)
+    assert nfrag > 0
+    fr0, fr2 = pack.frags[0], pack.frags[2]
+    assert pack.lookup(ws[0], torch.float32 if dtype == torch.bfloat16 else torch.bfloat16, *fr0) is None
     ws[2].mul_(2.0)                                   # torch-side update: version counter moves -> miss until refreshed
-    assert pack.lookup(ws[2], dtype) is None
+    assert pack.lookup(ws[2], dtype, *fr2) is None
     pack.refresh()
-    wf, wd = ops.pack_w3x3(ws[2], dtype, True)
-    hit = pack.lookup(ws[2], dtype)
+    wf, wd = ops.pack_w3x3(ws[2], dtype, True, None, *fr2)
+    hit = pack.lookup(ws[2], dtype, *fr2)
     assert torch.equal(hit[0], wf) and torch.equal(hit[1], wd)
     ops.WEIGHT_EPOCH += 1                             # raw-pointer optimizer update -> every entry is stale
-    assert pack.lookup(ws[0], dtype) is None
+    assert pack.lookup(ws[0], dtype, *fr0) is None
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 32, 32, 64, 0, 128), (2, 17, 23, 64, 64, 64), (1, 40, 24, 128, 128, 128),

@@ -15,6 +15,7 @@ HEADER = os.path.join(ROOT, "include", "unet_hip.h")
 LIB_PATH = os.environ.get("UH_LIB_PATH") or os.path.join(PKG_DIR, "libunet_hip.so")
 
 UH_F32, UH_BF16, UH_F32X3 = 0, 1, 2
+UH_WFRAG, UH_WFRAG_D = 0x100, 0x200      # fragment-major filter packs (include/unet_hip.h)
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,

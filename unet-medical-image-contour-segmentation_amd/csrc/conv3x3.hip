@@ -23,9 +23,42 @@
 // =====================================================================================
 // weight (un)packing
 // =====================================================================================
+// Two layouts of a packed filter [rows O][9 taps][K input channels]:
+//   KRSC            element (o, tap, k) at (o * 9 + tap) * K + k                          (every kernel reads it)
+//   fragment-major  (dt | UH_WFRAG) 1 KiB blocks = one MFMA A-fragment as the LDS-DMA MFMA kernel consumes it: block
+//                   ((g * 9 + tap) * (K / CK) + chunk), lane = kpart * 16 + m holds the 16 bytes
+//                   (row(g, m), tap, chunk * CK + kpart * VEC ...): a fragment load of the conv kernel is 1 KiB of
+//                   CONTIGUOUS memory (8 whole cache lines) instead of 16 rows x 64 bytes (16 half lines) -- the vector
+//                   memory path (TA / L1), not the matrix pipe, was what the forward kernel waited for.
+// row(g, m) = which filter row MFMA row m of 16-row group g holds; the conv kernel hands rows to the MFMAs in an order that
+// makes a lane's accumulators 16-byte pieces of the NHWC output (conv3x3_fwd_mfma_v2):
+//   bf16, O % 128 == 0:  32-row groups G = g >> 1, n = g & 1:  row = 32 G + (m >> 2) * 8 + n * 4 + (m & 3)
+//   bf16, otherwise:     row = 16 g + cg(m >> 2) * 4 + (m & 3),  cg = {0, 2, 1, 3}
+//   fp32:                row = 16 g + m
+__host__ __device__ __forceinline__ int uh_wfrag_mode(int es, int rows) { return es == 2 ? ((rows % 128 == 0) ? 2 : 1) : 0; }
+template <int ES>
+__device__ __forceinline__ int64_t uh_wfrag_index(int o, int tap, int k, int K, int mode) {
+    constexpr int CK = 64 / ES, VEC = 16 / ES;
+    int g, m;
+    if (mode == 2) {
+        const int c32 = o & 31;
+        g = ((o >> 5) << 1) | ((c32 >> 2) & 1);
+        m = ((c32 >> 3) << 2) | (c32 & 3);
+    } else if (mode == 1) {
+        const int c16 = o & 15, q = c16 >> 2;
+        g = o >> 4;
+        m = ((((q & 1) << 1) | (q >> 1)) << 2) | (c16 & 3);
+    } else {
+        g = o >> 4;
+        m = o & 15;
+    }
+    const int chunk = k / CK, e = k - chunk * CK, kp = e / VEC, v = e - kp * VEC;
+    return ((((int64_t)g * 9 + tap) * (K / CK) + chunk) * 64 + (kp * 16 + m)) * VEC + v;
+}
+
 template <typename T>
 __global__ void pack_w3x3_kernel(const float* __restrict__ w, int64_t sO, int64_t sI, int64_t sH, int64_t sW,
-                                 int Cout, int Cin, T* __restrict__ wf, T* __restrict__ wd) {
+                                 int Cout, int Cin, T* __restrict__ wf, T* __restrict__ wd, int frag_f, int frag_d) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)Cout * 9 * Cin;
     if (idx >= total) return;
@@ -34,8 +67,13 @@ __global__ void pack_w3x3_kernel(const float* __restrict__ w, int64_t sO, int64_
     int o = (int)(idx / (9 * (int64_t)Cin));
     int r = t / 3, s = t - 3 * r;
     float v = w[o * sO + i * sI + r * sH + s * sW];
-    wf[idx] = uh_from_f32<T>(v);
-    if (wd) wd[(((int64_t)i * 3 + (2 - r)) * 3 + (2 - s)) * Cout + o] = uh_from_f32<T>(v);
+    wf[frag_f ? uh_wfrag_index<(int)sizeof(T)>(o, t, i, Cin, uh_wfrag_mode(sizeof(T), Cout)) : idx] = uh_from_f32<T>(v);
+    if (wd) {
+        const int td = (2 - r) * 3 + (2 - s);
+        const int64_t k = frag_d ? uh_wfrag_index<(int)sizeof(T)>(i, td, o, Cout, uh_wfrag_mode(sizeof(T), Cin))
+                                 : ((int64_t)i * 9 + td) * Cout + o;
+        wd[k] = uh_from_f32<T>(v);
+    }
 }
 
 __global__ void unpack_dw3x3_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int64_t sO, int64_t sI,
@@ -71,9 +109,20 @@ __global__ void pack_w3x3_split_kernel(const float* __restrict__ w, int64_t sO, 
     }
 }
 
+// can a [rows][9][K] filter be packed fragment-major for element size es?
+static inline bool uh_wfrag_shape_ok(int rows, int K, int es) { return rows % 16 == 0 && K % (64 / es) == 0; }
+
 extern "C" int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, int64_t sW, int Cout, int Cin,
                             void* w_fwd, void* w_dgrad, int dt, uh_stream stream) {
     UH_REQUIRE(w && w_fwd && Cout > 0 && Cin > 0, "uh_pack_w3x3: bad arguments");
+    // dt | UH_WFRAG: fragment-major forward copy; dt | UH_WFRAG_D: fragment-major backward-data copy
+    const int frag_f = (dt & UH_WFRAG) ? 1 : 0, frag_d = (dt & UH_WFRAG_D) ? 1 : 0;
+    dt &= ~(UH_WFRAG | UH_WFRAG_D);
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_pack_w3x3: bad dtype %d", dt);
+    UH_REQUIRE(!(frag_f || frag_d) || dt != UH_F32X3, "uh_pack_w3x3: bf16x3 packs are KRSC only");
+    const int es_ = dt == UH_BF16 ? 2 : 4;
+    UH_REQUIRE(!frag_f || uh_wfrag_shape_ok(Cout, Cin, es_), "uh_pack_w3x3: fragment-major forward pack needs Cout %% 16 == 0 and Cin %% %d == 0", 64 / es_);
+    UH_REQUIRE(!frag_d || uh_wfrag_shape_ok(Cin, Cout, es_), "uh_pack_w3x3: fragment-major backward-data pack needs Cin %% 16 == 0 and Cout %% %d == 0", 64 / es_);
     int64_t total = (int64_t)Cout * 9 * Cin;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -85,10 +134,10 @@ extern "C" int uh_pack_w3x3(const float* w, int64_t sO, int64_t sI, int64_t sH, 
     }
     if (dt == UH_BF16)
         hipLaunchKernelGGL(pack_w3x3_kernel<bf16_t>, grid, block, 0, st, w, sO, sI, sH, sW, Cout, Cin,
-                           (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+                           (bf16_t*)w_fwd, (bf16_t*)w_dgrad, frag_f, frag_d);
     else
         hipLaunchKernelGGL(pack_w3x3_kernel<float>, grid, block, 0, st, w, sO, sI, sH, sW, Cout, Cin,
-                           (float*)w_fwd, (float*)w_dgrad);
+                           (float*)w_fwd, (float*)w_dgrad, frag_f, frag_d);
     UH_CHECK_LAUNCH("uh_pack_w3x3");
     return UH_OK;
 }
@@ -155,6 +204,7 @@ __global__ __launch_bounds__(256) void pack_w3x3_batched_kernel(const long long*
         const long long sO = e[1], sI = e[2], sH = e[3], sW = e[4];
         const int Cout = (int)e[5], Cin = (int)e[6];
         const long long base = e[7];
+        const int frag_f = (int)(e[9] & 1), frag_d = (int)((e[9] >> 1) & 1);      // fragment-major copies (see uh_wfrag_index)
         const int ti = (Cin + 31) >> 5, to = (Cout + 31) >> 5;
         long long k = tl - e[8];
         const int it = (int)(k % ti); k /= ti;
@@ -169,7 +219,9 @@ __global__ __launch_bounds__(256) void pack_w3x3_batched_kernel(const long long*
             float v = 0.f;
             if (o < Cout && i < Cin) {
                 v = w[o * sO + i * sI + r * sH + s_ * sW];
-                wf[base + ((long long)o * 9 + t) * Cin + i] = uh_from_f32<T>(v);
+                const long long k = frag_f ? uh_wfrag_index<(int)sizeof(T)>(o, t, i, Cin, uh_wfrag_mode(sizeof(T), Cout))
+                                           : ((long long)o * 9 + t) * Cin + i;
+                wf[base + k] = uh_from_f32<T>(v);
             }
             tile[rr][tx] = v;
         }
@@ -179,7 +231,11 @@ __global__ __launch_bounds__(256) void pack_w3x3_batched_kernel(const long long*
 #pragma unroll
             for (int rr = ty; rr < 32; rr += 8) {
                 const int i = i0 + rr, o = o0 + tx;
-                if (i < Cin && o < Cout) wd[base + ((long long)i * 9 + td) * Cout + o] = uh_from_f32<T>(tile[tx][rr]);
+                if (i < Cin && o < Cout) {
+                    const long long k = frag_d ? uh_wfrag_index<(int)sizeof(T)>(i, td, o, Cout, uh_wfrag_mode(sizeof(T), Cin))
+                                               : ((long long)i * 9 + td) * Cout + o;
+                    wd[base + k] = uh_from_f32<T>(tile[tx][rr]);
+                }
             }
         }
     }
@@ -487,7 +543,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
-    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv) {
+    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv, int wfrag) {
     // C0 / C1 / Cout are the channel counts the filter pack is laid out for (multiples of a chunk / of 64); C0v / C1v /
     // Coutv (<=) are the channels that exist in memory ("narrow" tensors of the small-width nets): input channels
     // beyond them are fetched as zeros by the DMA, output channels beyond Coutv are computed (zero filters) but not stored.
@@ -528,7 +584,6 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         tile_lane = blockIdx.x - slab * nlanes;
     }
     const int co_blk = slab * BN;
-    const int co_w = co_blk + wave * (NBW * 16);
     const int Cin = C0 + C1;
     // K-chunks that hold at least one stored channel: chunks beyond a source's valid count (narrow tensors) would be all
     // zeros, so they are neither fetched nor multiplied.  Ordinary tensors: nch0 + nch1 == Cin / CK, chunk_of(v) == v.
@@ -585,6 +640,10 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
                 for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(rel0[k] + base);
                 if (tid + (NLOAD - 1) * 256 >= NPIECE) voff[NLOAD - 1] = OOB_OFFSET;
+#ifdef UH_ABL_DMACOAL    // timing-only: contiguous 1 KiB per wave instruction
+#pragma unroll
+                for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(base + (d_y0 * W) * 0 + tid * 16 + k * 4096 + ((d_y0 + 1) * W + d_x0) * 0);
+#endif
             } else {
                 // (the opaque copy of tid keeps the per-slot coordinates from being hoisted out of the tile loop into 12
                 // long-lived registers: the main loop runs at the register limit)
@@ -619,19 +678,27 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     // Which output channel an MFMA row holds.  The 16 rows of MFMA n land in the accumulator as 4 consecutive rows per lane
     // group kg (acc[i][n][j] = row kg*4 + j, pixel lx).  The filter rows are handed to the MFMAs in a PERMUTED order so that
     // what a lane holds for one pixel is one 16-byte piece of the NHWC output and the epilogue stores straight from the
-    // registers (no LDS bounce, no barrier):
-    //   bf16, NBW = 2:  row m of MFMA n = channel (m >> 2) * 8 + n * 4 + (m & 3): a lane's (n, j) values are 8 consecutive
-    //                   channels kg*8 .. kg*8+7 -> one 16-byte store per lane and pixel row, 64 contiguous bytes per pixel;
-    //   bf16, NBW = 1:  row m = channel cg(m >> 2) * 4 + (m & 3) with cg = {0, 2, 1, 3}: lanes l and l + 32 hold adjacent
-    //                   4-channel groups, so ONE v_permlane32_swap per dword pairs two pixel rows into 16-byte stores;
-    //   fp32:           the MFMA's own order (a lane's 4 channels of one MFMA are 16 bytes already).
-    constexpr bool PERM2 = (ES == 2 && NBW == 2), PERM1 = (ES == 2 && NBW == 1);
-    auto chan_of = [&](int grp, int n, int j) -> int {       // grp = row >> 2 (= kg for accumulators), j = row & 3
-        if constexpr (PERM2) return grp * 8 + n * 4 + j;
-        else if constexpr (PERM1) return ((((grp & 1) << 1) | (grp >> 1)) << 2) + j;
-        else return n * 16 + grp * 4 + j;
+    // registers (no LDS bounce, no barrier).  ch(grp, n, j) = channel - co_blk of row grp*4 + j of the wave's MFMA n:
+    //   bf16, NBW = 2:                  wave*32 + grp*8 + n*4 + j: a lane's (n, j) values are 8 consecutive channels ->
+    //                                   one 16-byte store per lane and pixel row, 64 contiguous bytes per pixel;
+    //   bf16, NBW = 1, Cout % 128 != 0: wave*16 + cg(grp)*4 + j with cg = {0, 2, 1, 3}: lanes l and l + 32 hold adjacent
+    //                                   4-channel groups, so ONE v_permlane32_swap per dword pairs two pixel rows into
+    //                                   16-byte stores;
+    //   bf16, NBW = 1, Cout % 128 == 0: (small feature maps of wide layers) the row order of the NBW = 2 case, the wave
+    //                                   holding one of its two MFMAs: (wave>>1)*32 + grp*8 + (wave&1)*4 + j, 8-byte stores --
+    //                                   so that the row order, and with it the fragment-major filter pack (uh_wfrag_index),
+    //                                   depends on the dtype and Cout only, not on which instantiation a launch picks;
+    //   fp32:                           the MFMA's own order wave*16*NBW + n*16 + grp*4 + j (16 bytes per lane already).
+    constexpr bool PERM2 = (ES == 2 && NBW == 2);
+    const bool half32 = (ES == 2 && NBW == 1) && (Cout % 128 == 0);
+    const bool perm1 = (ES == 2 && NBW == 1) && !half32;
+    auto ch = [&](int grp, int n, int j) -> int {       // grp = row >> 2 (= kg for accumulators), j = row & 3
+        if constexpr (PERM2) return wave * 32 + grp * 8 + n * 4 + j;
+        else if constexpr (ES == 2) return half32 ? ((wave >> 1) * 32 + grp * 8 + (wave & 1) * 4 + j)
+                                                  : (wave * 16 + ((((grp & 1) << 1) | (grp >> 1)) << 2) + j);
+        else return wave * (16 * NBW) + n * 16 + grp * 4 + j;
     };
-    const int wrow0 = co_w + chan_of(lx >> 2, 0, lx & 3);
+    const int wrow0 = co_blk + ch(lx >> 2, 0, lx & 3);
     const int64_t wnb_stride = (int64_t)(PERM2 ? 4 : 16) * 9 * Cin;
     // Filter fragments come through a buffer descriptor: ONE per-lane byte offset (the lane's filter row and 16-byte part)
     // plus a wave-uniform byte offset in an SGPR (chunk, tap, n) -- no 64-bit address arithmetic in vector registers -- as
@@ -639,15 +706,21 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     // SPLIT: `w` holds two bf16 arrays [Cout][9][Cin] (hi then lo); a fragment = 4 hi values + 4 lo values (two 8-byte loads).
     const int64_t wlo_off = (int64_t)Cout * 9 * Cin;
     const u32x4 rsw = uh_desc_words(w, (unsigned)((int64_t)Cout * 9 * Cin * (SPLIT ? 4 : ES)));
-    const unsigned wvoff = (unsigned)(((int64_t)wrow0 * 9 * Cin + kg * (SPLIT ? 4 : VEC)) * (SPLIT ? 2 : ES));
+    const unsigned wvoff = wfrag ? (unsigned)(lane * 16)
+                                 : (unsigned)(((int64_t)wrow0 * 9 * Cin + kg * (SPLIT ? 4 : VEC)) * (SPLIT ? 2 : ES));
+    // fragment-major packs (uh_wfrag_index): block ((g * 9 + tap) * NCH + chunk) of 1 KiB, g = the wave's 16-row group
+    const int wg0 = (co_blk >> 4) + wave * NBW, nch_all = Cin / CK;
     struct WFrag { u32x4 v; u32x2 hi, lo; };     // non-SPLIT: v = the fragment; SPLIT: hi / lo = the bf16 halves of 4 values
     constexpr int NWLOAD = 3 * NBW * (SPLIT ? 2 : 1);      // load instructions per column shift (one weight set)
-    auto wfrag_async = [&](WFrag& dst, int64_t off) {    // off = n * wnb_stride + tap * Cin + chunk offset (elements)
+    auto wfrag_async = [&](WFrag& dst, int64_t off, int n, int tap, int chunk) {    // off = n * wnb_stride + tap * Cin + chunk offset (elements)
+        // ONE asm statement per destination: with a load in each arm of a branch the compiler merges the two "results"
+        // with register copies behind the branch -- executed before the data has arrived (asynchronous destination)
         if constexpr (SPLIT) {
             uh_ld8_async(dst.hi, rsw, wvoff, (int)(off * 2));
             uh_ld8_async(dst.lo, rsw, wvoff, (int)((off + wlo_off) * 2));
         } else {
-            uh_ld16_async(dst.v, rsw, wvoff, (int)(off * ES));
+            const int soff = wfrag ? ((((wg0 + n) * 9 + tap) * nch_all + chunk) << 10) : (int)(off * ES);
+            uh_ld16_async(dst.v, rsw, wvoff, soff);
         }
     };
     // fp32 pixel fragment (4 channels) -> {hi pair, hi pair, lo pair, lo pair} as bf16
@@ -687,11 +760,12 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             wA[r][n].v = wB[r][n].v = wC[r][n].v = u32x4{0u, 0u, 0u, 0u};
             wA[r][n].hi = wB[r][n].hi = wC[r][n].hi = wA[r][n].lo = wB[r][n].lo = wC[r][n].lo = u32x2{0u, 0u};
         }
-    auto load_w = [&](WFrag (&dst)[3][NBW], int64_t wsrc) {
+    auto load_w = [&](WFrag (&dst)[3][NBW], int chunk, int sft) {      // the three row taps of column shift `sft`, chunk `chunk`
+        const int64_t wsrc = (int64_t)chunk * CK + (int64_t)sft * Cin;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int n = 0; n < NBW; ++n) wfrag_async(dst[r][n], wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin);
+            for (int n = 0; n < NBW; ++n) wfrag_async(dst[r][n], wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin, n, r * 3 + sft, chunk);
     };
     int bufi = 0;
     // one column shift: rolling window over the 18 halo rows, row k+1 is fetched from LDS while output row k-2 is multiplied
@@ -741,7 +815,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 
     dma_tile(tile);
     dma_chunk(chunk_of(0), 0, true);
-    load_w(wA, (int64_t)chunk_of(0) * CK);
+    load_w(wA, chunk_of(0), 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
@@ -754,13 +828,13 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 
 #pragma unroll 1
         for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
-            const int64_t wcp = (int64_t)chunk_of(v) * CK;
-            const int64_t wcp_next = (int64_t)chunk_of((v + 1 < nchunk) ? v + 1 : 0) * CK;   // wraps to chunk 0 of the next tile
+            const int cur_c = chunk_of(v);
+            const int next_c = chunk_of((v + 1 < nchunk) ? v + 1 : 0);   // wraps to chunk 0 of the next tile
             const unsigned char* buf = lds + bufi * HALO2_STRIDE;
-            load_w(wB, wcp + (int64_t)Cin);
+            load_w(wB, cur_c, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_shift(buf, 0, wA);
-            load_w(wC, wcp + 2 * (int64_t)Cin);
+            load_w(wC, cur_c, 2);
             // the halo tile of what follows chunk v: the tile's next chunk, else chunk 0 of the workgroup's next tile, else
             // nothing (six out-of-range pieces keep the instruction count of the waits below)
             if (v + 1 < nchunk) {
@@ -772,7 +846,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             }
             UH_WAIT_VM(NWLOAD + NLOAD);               // WB landed (WC and the DMA stay in flight)
             mma_shift(buf, 1, wB);
-            load_w(wA, wcp_next);
+            load_w(wA, next_c, 0);
             UH_WAIT_VM(NLOAD + NWLOAD);               // WC landed (the DMA and WA' stay in flight)
             mma_shift(buf, 2, wC);
             // DMA and WA' landed; every wave has finished reading this buffer
@@ -787,7 +861,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             for (int n = 0; n < NBW; ++n) asm volatile("" :: "v"(acc[i][n]));
         continue;
 #endif
-        // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_w + chan_of(kg, n, j)]
+        // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_blk + ch(kg, n, j)]
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
         const int tyt = t % tilesY;
@@ -799,8 +873,8 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         if (ep_scale) {      // inference: eval-mode BatchNorm (per-channel scale/shift) + ReLU applied to the accumulators
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + co_w + chan_of(kg, n, 0));
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + co_w + chan_of(kg, n, 0));
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + co_blk + ch(kg, n, 0));
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + co_blk + ch(kg, n, 0));
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -824,7 +898,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             const int rbytes = W * ldy * ES;                                   // one image row of y
             const int sbase = ((b * H + y0) * W) * ldy * ES;                   // row 0 of the tile, column 0
             if constexpr (PERM2) {
-                const int c0 = co_w + kg * 8;
+                const int c0 = co_blk + ch(kg, 0, 0);
                 const bool inr = gx < W && c0 < Coutv;
                 const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
@@ -835,9 +909,9 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, inr ? voff + (unsigned)(sbase + i * rbytes) : OOB_OFFSET, 0, 0);
                     }
                 }
-            } else if constexpr (PERM1) {
+            } else if (perm1) {
                 // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
-                const int c0 = co_w + (kg & 1) * 8;
+                const int c0 = co_blk + wave * 16 + (kg & 1) * 8;
                 const int rsel = kg >> 1;
                 const bool inr = gx < W && c0 < Coutv;
                 const unsigned voff0 = (unsigned)((gx * ldy + c0) * ES + rsel * rbytes);
@@ -857,7 +931,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             } else {
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
-                    const int c0 = co_w + chan_of(kg, n, 0);
+                    const int c0 = co_blk + ch(kg, n, 0);
                     const bool inr = gx < W && c0 < Coutv;
                     const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
@@ -879,9 +953,9 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         // ---- BatchNorm statistics: pivot-shifted sums per lane, 4 DPP adds per channel, accumulated in LDS by the lane that
         // owns the channel's slot (the same lane every tile: no barrier, a wave only touches its own channels)
         if (stats) {
-            float* S1 = &wg_sum[0][wave * (NBW * 16)];
-            float* S2 = &wg_sum[1][wave * (NBW * 16)];
-            float* PV = &wg_sum[2][wave * (NBW * 16)];
+            float* S1 = &wg_sum[0][0];          // slot = channel - co_blk: a wave touches its own channels only
+            float* S2 = &wg_sum[1][0];
+            float* PV = &wg_sum[2][0];
             if (n_run == 0.f) {
                 // pivot = the tile's first stored value of each channel (pixel (0,0): lane lx == 0 of every lane group)
                 if (lx == 0) {
@@ -889,7 +963,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                     for (int n = 0; n < NBW; ++n)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int cl = chan_of(kg, n, j);
+                            const int cl = ch(kg, n, j);
                             PV[cl] = acc[0][n][j];
                             S1[cl] = 0.f;
                             S2[cl] = 0.f;
@@ -899,7 +973,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             // one channel at a time (3 live temporaries instead of 3 per channel: the epilogue runs at the register limit)
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[chan_of(kg, n, 0)]);      // same-wave LDS write -> read: in order
+                const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[ch(kg, n, 0)]);      // same-wave LDS write -> read: in order
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float pv = q[j];
@@ -921,7 +995,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                     }
                     const float a1 = uh_row16_sum(s1), a2 = uh_row16_sum(s2);   // lanes of one kg = one DPP row
                     if (lx == 0) {
-                        const int cl = chan_of(kg, n, j);
+                        const int cl = ch(kg, n, j);
                         S1[cl] += a1;
                         S2[cl] += a2;
                     }
@@ -939,7 +1013,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int cl = wave * (NBW * 16) + chan_of(kg, n, j);
+                    const int cl = ch(kg, n, j);
                     const float a1 = wg_sum[0][cl], a2 = wg_sum[1][cl];
                     stats[((int64_t)tile_lane * 2 + 0) * Cout + co_blk + cl] = wg_sum[2][cl] + a1 * inv_n;      // mean
                     stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = fmaxf(a2 - a1 * a1 * inv_n, 0.f); // M2
@@ -1374,7 +1448,7 @@ template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
                                 const float* ep_shift, bool* ep_done, bool split = false, int C0v = -1, int C1v = -1,
-                                int Coutv = -1) {
+                                int Coutv = -1, bool wfrag = false) {
     const bool narrow = C0v >= 0;          // narrow tensors: only the LDS-DMA MFMA kernel implements the channel masks
     if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
@@ -1405,29 +1479,32 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             if (ep_scale && !(uh_aligned16(ep_scale) && uh_aligned16(ep_shift))) ep_scale = ep_shift = nullptr;   // 16-B loads
             constexpr bool CAN_SPLIT = (ES == 4);
             if (split && !CAN_SPLIT) { uh_set_error("conv3x3_fwd: bf16x3 needs fp32 tensors"); return UH_EINVAL; }
+            if (split && wfrag) { uh_set_error("conv3x3_fwd: bf16x3 filters are KRSC packs"); return UH_EINVAL; }
+            if (narrow && wfrag) { uh_set_error("conv3x3_fwd: narrow-tensor calls take KRSC packs"); return UH_EINVAL; }
             if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
                 if (split) {
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
-                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
-                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv);
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
             }
             UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2");
             *ep_done = ep_scale != nullptr;
             return UH_OK;
         }
+        if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but this call cannot take the LDS-DMA MFMA kernel (a tensor of 2 GiB or more); ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
         if (split) { uh_set_error("conv3x3_fwd: bf16x3 is implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors are implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (Cout % 128 == 0) {
@@ -1440,6 +1517,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         UH_CHECK_LAUNCH("conv3x3_fwd_mfma");
         return UH_OK;
     }
+    if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but the shape / alignment is outside the MFMA path; ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
     if (split) { uh_set_error("conv3x3_fwd: bf16x3 needs an MFMA-aligned shape (Cin %% 16 == 0, Cout %% 64 == 0, 16-byte strides)"); return UH_EINVAL; }
     if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors need padded counts that are MFMA-aligned and 16-byte strides"); return UH_EINVAL; }
     if (Cin <= 4 && C1 == 0) {
@@ -1489,14 +1567,33 @@ extern "C" int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, i
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd: bad shape");
     UH_REQUIRE(ld0 >= C0 && ldy >= Cout && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_fwd: bad strides");
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd: pixel count overflows int32");
+    const bool wfrag = (dt & UH_WFRAG) != 0;          // the filter pack is fragment-major (uh_pack_w3x3 with the same flag)
+    dt &= ~UH_WFRAG;
     UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_fwd: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
     bool done;
     if (dt == UH_BF16)
         return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w,
-                                            (bf16_t*)y, ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done);
+                                            (bf16_t*)y, ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done, false,
+                                            -1, -1, -1, wfrag);
     return conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)y,
-                                       ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done, dt == UH_F32X3);
+                                       ldy, Cout, stat_partials, B, H, W, st, nullptr, nullptr, &done, dt == UH_F32X3, -1, -1,
+                                       -1, wfrag);
+}
+
+// Will uh_conv3x3_fwd take the LDS-DMA MFMA kernel for this call (pointers assumed 16-byte aligned)?  Only then may the
+// filter be packed fragment-major (dt | UH_WFRAG in uh_pack_w3x3 and in the conv call): 8 whole cache lines per fragment
+// load instead of 16 half lines.
+extern "C" int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout, int ld0, int ld1, int ldy, int dt) {
+    if (dt != UH_F32 && dt != UH_BF16) return 0;
+    const int es = dt == UH_BF16 ? 2 : 4, ck = 64 / es;
+    if (B <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    if (C0 % ck || C1 % ck || Cout % 64) return 0;
+    if ((ld0 * es) % 16 || (C1 && (ld1 * es) % 16) || (ldy * es) % 16) return 0;
+    const int64_t px = (int64_t)B * H * W, lim = (1ll << 31) - 4096;
+    if (px * ld0 * es >= lim || (C1 && px * ld1 * es >= lim) || px * ldy * es >= lim) return 0;
+    if ((int64_t)Cout * 9 * (C0 + C1) * es >= lim) return 0;
+    return 1;
 }
 
 // Inference forward: z = max(conv(x, w) * scale + shift, 0) with the eval-mode BatchNorm coefficients of
@@ -1509,16 +1606,18 @@ extern "C" int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_fwd_affine_relu: bad shape");
     UH_REQUIRE(ld0 >= C0 && ldz >= Cout && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_fwd_affine_relu: bad strides");
     UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd_affine_relu: pixel count overflows int32");
+    const bool wfrag = (dt & UH_WFRAG) != 0;
+    dt &= ~UH_WFRAG;
     UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_fwd_affine_relu: bad dtype %d", dt);
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     int rc;
     if (dt == UH_BF16)
         rc = conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1, ld1, (const bf16_t*)w,
-                                          (bf16_t*)z, ldz, Cout, nullptr, B, H, W, st, scale, shift, &done);
+                                          (bf16_t*)z, ldz, Cout, nullptr, B, H, W, st, scale, shift, &done, false, -1, -1, -1, wfrag);
     else
         rc = conv3x3_fwd_dispatch<float>((const float*)x0, C0, ld0, (const float*)x1, C1, ld1, (const float*)w, (float*)z,
-                                         ldz, Cout, nullptr, B, H, W, st, scale, shift, &done, dt == UH_F32X3);
+                                         ldz, Cout, nullptr, B, H, W, st, scale, shift, &done, dt == UH_F32X3, -1, -1, -1, wfrag);
     if (rc != UH_OK || done) return rc;
     return uh_bn_relu_apply(z, ldz, scale, shift, z, ldz, (int64_t)B * H * W, Cout, dt == UH_BF16 ? UH_BF16 : UH_F32, stream);
 }

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 from torch.autograd import Function
 
-from ._lib import LIB, UH_BF16, UH_F32, UH_F32X3
+from ._lib import LIB, UH_BF16, UH_F32, UH_F32X3, UH_WFRAG, UH_WFRAG_D
 
 BN_EPS_DEFAULT = 1e-5
 
@@ -164,7 +164,21 @@ def conv_dt(x: torch.Tensor, C0: int, C1: int, Cout: int, need_dx: bool) -> int:
     return _dt(x)
 
 
-def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool, dt_code: Optional[int] = None):
+# Use fragment-major filter packs (UH_WFRAG) wherever the LDS-DMA MFMA kernel runs (False: KRSC everywhere, for A/B runs).
+WFRAG = True
+
+
+def wfrag_ok(B: int, H: int, W: int, C0: int, C1: int, Cout: int, ld0: int, ld1: int, ldy: int, dt: int) -> bool:
+    """May the filter of this conv call be packed fragment-major?  (dt: UH_F32 / UH_BF16; bf16x3 packs are KRSC.)"""
+    if not WFRAG or dt not in (UH_F32, UH_BF16):
+        return False
+    return bool(LIB.query("uh_conv3x3_wfrag_ok", B, H, W, C0, C1, Cout, ld0, ld1, ldy, dt))
+
+
+def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool, dt_code: Optional[int] = None,
+              frag_f: bool = False, frag_d: bool = False):
+    """-> (forward pack, backward-data pack or None); frag_f / frag_d: fragment-major instead of KRSC (the conv call that
+    consumes the pack must then pass wfrag=True)."""
     O, I = weight.shape[0], weight.shape[1]
     w32 = weight if weight.dtype == torch.float32 else weight.float()
     wf = torch.empty(O * 9 * I, dtype=dtype, device=weight.device)
@@ -172,7 +186,8 @@ def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool, dt_cod
     sO, sI, sH, sW = w32.stride()
     if dt_code is None:
         dt_code = UH_BF16 if dtype == torch.bfloat16 else UH_F32
-    LIB.call("uh_pack_w3x3", w32.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), _p(wd), dt_code, _stream())
+    flags = (UH_WFRAG if frag_f else 0) | (UH_WFRAG_D if (frag_d and need_dgrad) else 0)
+    LIB.call("uh_pack_w3x3", w32.data_ptr(), sO, sI, sH, sW, O, I, wf.data_ptr(), _p(wd), dt_code | flags, _stream())
     return wf, wd
 
 
@@ -181,17 +196,18 @@ def pack_w3x3(weight: torch.Tensor, dtype: torch.dtype, need_dgrad: bool, dt_cod
 WEIGHT_EPOCH = 0
 
 
-def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """KRSC filter pack for the inference forward, cached on the parameter until it changes."""
+def packed_w3x3_cached(weight: torch.Tensor, dtype: torch.dtype, frag: bool = False) -> torch.Tensor:
+    """Filter pack (KRSC, or fragment-major with frag=True) for the inference forward, cached on the parameter until it
+    changes."""
     try:
         version = weight._version
     except RuntimeError:                      # a temporary created under torch.inference_mode (zero-padded small-width filter)
-        return pack_w3x3(weight, dtype, False)[0]
-    key = (weight.data_ptr(), version, WEIGHT_EPOCH, dtype, tuple(weight.stride()))
+        return pack_w3x3(weight, dtype, False, frag_f=frag)[0]
+    key = (weight.data_ptr(), version, WEIGHT_EPOCH, dtype, tuple(weight.stride()), frag)
     hit = getattr(weight, "_uh_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    wf, _ = pack_w3x3(weight, dtype, False)
+    wf, _ = pack_w3x3(weight, dtype, False, frag_f=frag)
     try:
         weight._uh_packed = (key, wf)
     except AttributeError:
@@ -242,10 +258,17 @@ class ConvWeightPack:
         dev = self.weights[0].device
         rows, off, toff = [], 0, 0
         self.offsets = []
+        ck = 32 if self.dtype == torch.bfloat16 else 16          # channels per 64-byte K chunk
+        self.frags = []
         for w in self.weights:
             O, I = w.shape[0], w.shape[1]
             sO, sI, sH, sW = w.stride()
-            rows.append([w.data_ptr(), sO, sI, sH, sW, O, I, off, toff, 0])
+            # fragment-major copies where the LDS-DMA MFMA kernel will consume them (uh_conv3x3_wfrag_ok's channel rules;
+            # the caller of lookup() states what its conv call needs and packs for itself when that differs)
+            ff = WFRAG and O % 64 == 0 and I % ck == 0
+            fd = WFRAG and I % 64 == 0 and O % ck == 0
+            self.frags.append((ff, fd))
+            rows.append([w.data_ptr(), sO, sI, sH, sW, O, I, off, toff, (1 if ff else 0) | (2 if fd else 0)])
             self.offsets.append(off)
             off += O * 9 * I
             toff += ((O + 31) // 32) * ((I + 31) // 32) * 9
@@ -267,13 +290,14 @@ class ConvWeightPack:
         self.versions = [w._version for w in self.weights]
         self.epoch = WEIGHT_EPOCH
 
-    def lookup(self, weight: torch.Tensor, dtype: torch.dtype):
-        """-> (w_fwd, w_dgrad) views if the pack holds the CURRENT value of `weight` in `dtype`, else None."""
+    def lookup(self, weight: torch.Tensor, dtype: torch.dtype, frag_f: bool = False, frag_d: bool = False):
+        """-> (w_fwd, w_dgrad) views if the pack holds the CURRENT value of `weight` in `dtype` in the layouts the caller's
+        conv calls need (frag_f / frag_d: fragment-major forward / backward-data copy), else None."""
         if FP32_MODE != "exact" and dtype == torch.float32:
             return None                          # bf16x3 layers pack their own [hi | lo] copies
         i = self.index.get(weight.data_ptr())
         if i is None or dtype != self.dtype or self.epoch != WEIGHT_EPOCH or self.versions[i] != weight._version \
-                or self.strides[i] != tuple(weight.stride()):
+                or self.strides[i] != tuple(weight.stride()) or self.frags[i] != (bool(frag_f), bool(frag_d)):
             return None
         n = weight.shape[0] * 9 * weight.shape[1]
         o = self.offsets[i]
@@ -285,7 +309,7 @@ WEIGHT_PACK: Optional[ConvWeightPack] = None
 
 
 def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, Cout: int,
-                want_stats: bool, dt_code: Optional[int] = None):
+                want_stats: bool, dt_code: Optional[int] = None, wfrag: bool = False):
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     dt = _dt(x0) if dt_code is None else dt_code
@@ -297,7 +321,7 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
     name = "conv3x3_fwd_" + _variant((C0, C1), Cout, x0.element_size())
     with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1)):
         LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
-                 w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt, _stream())
+                 w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt | (UH_WFRAG if wfrag else 0), _stream())
     return y, stats, nslab
 
 
@@ -332,9 +356,11 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
     dyv = torch.randn(B, H, W, Cout, generator=g).to(dev, dtype)
     w1 = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
     w2 = (torch.randn(Cout, Cout, 3, 3, generator=g) / (3 * Cout ** 0.5)).to(dev)
-    w1f, w1d = pack_w3x3(w1, dtype, True)
-    w2f, w2d = pack_w3x3(w2, dtype, True)
     dt = _dt(x)
+    fr = {"f1": wfrag_ok(B, H, W, Cin, 0, Cout, Cin, 0, Cout, dt), "d1": wfrag_ok(B, H, W, Cout, 0, Cin, Cout, 0, Cin, dt),
+          "f2": wfrag_ok(B, H, W, Cout, 0, Cout, Cout, 0, Cout, dt)}
+    w1f, w1d = pack_w3x3(w1, dtype, True, frag_f=fr["f1"], frag_d=fr["d1"])
+    w2f, w2d = pack_w3x3(w2, dtype, True, frag_f=fr["f2"], frag_d=fr["f2"])
     yo = torch.empty(B, H, W, Cout, dtype=dtype, device=dev)
     xo = torch.empty(B, H, W, Cin, dtype=dtype, device=dev)
     nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cin, Cout, dt)
@@ -345,9 +371,9 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = _stream()
 
-    def fwd(src, cin, wp, dst, cout, stat):
+    def fwd(src, cin, wp, dst, cout, stat, frag=False):
         LIB.call("uh_conv3x3_fwd", src.data_ptr(), cin, cin, None, 0, 0, wp.data_ptr(), dst.data_ptr(), cout, cout,
-                 _p(stat), B, H, W, dt, st)
+                 _p(stat), B, H, W, dt | (UH_WFRAG if frag else 0), st)
 
     def wgrad(dy, src, cin):
         LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), Cout, src.data_ptr(), cin, cin, None, 0, 0, dw.data_ptr(), Cout,
@@ -369,10 +395,10 @@ def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.
     f2 = 2.0 * B * H * W * Cout * 9 * Cout
     out = {
         "shape": f"B{B} {H}x{W} {Cin}->{Cout}->{Cout} {str(dtype)[6:]}",
-        "fwd_conv1": timeit(lambda: fwd(x, Cin, w1f, yo, Cout, stats), f1),
-        "fwd_conv2": timeit(lambda: fwd(h, Cout, w2f, yo, Cout, stats), f2),
-        "dgrad_conv2": timeit(lambda: fwd(dyv, Cout, w2d, yo, Cout, None), f2),
-        "dgrad_conv1": timeit(lambda: fwd(dyv, Cout, w1d, xo, Cin, None), f1),
+        "fwd_conv1": timeit(lambda: fwd(x, Cin, w1f, yo, Cout, stats, fr["f1"]), f1),
+        "fwd_conv2": timeit(lambda: fwd(h, Cout, w2f, yo, Cout, stats, fr["f2"]), f2),
+        "dgrad_conv2": timeit(lambda: fwd(dyv, Cout, w2d, yo, Cout, None, fr["f2"]), f2),
+        "dgrad_conv1": timeit(lambda: fwd(dyv, Cout, w1d, xo, Cin, None, fr["d1"]), f1),
         "wgrad_conv2": timeit(lambda: wgrad(dyv, h, Cout), f2),
         "wgrad_conv1": timeit(lambda: wgrad(dyv, x, Cin), f1),
     }
@@ -434,14 +460,19 @@ class ConvBnReluFn(Function):
             raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
         need_dx = any(ctx.needs_input_grad[:2])
         cdt = conv_dt(x0, C0, C1, Cout, need_dx and training)
+        # fragment-major filter packs where the LDS-DMA MFMA kernel runs (forward: this call; backward-data: the conv of dy
+        # [B,H,W,Cout] with the transposed filter into dx [B,H,W,Cin])
+        frag_f = wfrag_ok(B, H, W, C0, C1, Cout, pixel_ld(x0), 0 if x1 is None else pixel_ld(x1), Cout, cdt)
+        frag_d = bool(need_dx and training) and wfrag_ok(B, H, W, Cout, 0, Cin, Cout, 0, Cin, cdt)
         if training:
-            hit = WEIGHT_PACK.lookup(weight, x0.dtype) if (WEIGHT_PACK is not None and cdt != UH_F32X3) else None
-            wf, wd = hit if hit is not None else pack_w3x3(weight, x0.dtype, need_dx, cdt)
+            hit = WEIGHT_PACK.lookup(weight, x0.dtype, frag_f, frag_d) if (WEIGHT_PACK is not None and cdt != UH_F32X3) else None
+            wf, wd = hit if hit is not None else pack_w3x3(weight, x0.dtype, need_dx, cdt, frag_f, frag_d)
         elif cdt == UH_F32X3:
             wf, wd = pack_w3x3(weight, x0.dtype, False, cdt)[0], None
         else:
-            wf, wd = packed_w3x3_cached(weight, x0.dtype), None
+            wf, wd = packed_w3x3_cached(weight, x0.dtype, frag_f), None
         ctx.cdt = cdt
+        ctx.frag_d = frag_d
         dev = x0.device
         coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
         scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
@@ -451,7 +482,7 @@ class ConvBnReluFn(Function):
         if training:
             global BN_STATS_EPOCH
             BN_STATS_EPOCH += 1                   # running statistics are about to change under torch's feet
-            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt)
+            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt, frag_f)
             nbt = num_batches_tracked
             fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
             nbt_ptr = nbt.data_ptr() if fused_nbt else None
@@ -476,7 +507,7 @@ class ConvBnReluFn(Function):
             z = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=dev)
             LIB.call("uh_conv3x3_fwd_affine_relu", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
                      pixel_ld(x1) if x1 is not None else 0, wf.data_ptr(), z.data_ptr(), Cout, Cout, scale.data_ptr(),
-                     shift.data_ptr(), B, H, W, cdt, _stream())
+                     shift.data_ptr(), B, H, W, cdt | (UH_WFRAG if frag_f else 0), _stream())
             ctx.training = False
             return z
         z = torch.empty_like(y)
@@ -530,7 +561,7 @@ class ConvBnReluFn(Function):
         # layer's own MFMA-bound backward-data.
         dx0 = dx1 = None
         if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt)
+            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt, ctx.frag_d)
             dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
             dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
