@@ -1935,34 +1935,46 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // padding through the descriptor range check) and double buffered: the DMA of tile t+1 is issued right after
 // the barrier that retires tile t-1 and lands under the 72 MFMAs per wave of tile t.
 // =====================================================================================
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
+// NWR = number of 32-row output-channel blocks of the workgroup tile: 2 -> 64 co x 64 ci, 4 waves, two workgroups per CU;
+// 4 -> 128 co x 64 ci, 8 waves, one workgroup per CU: the x halo image (the operand with the 1.4x halo) is staged once for
+// twice the MFMA work, 30 % fewer DMA bytes / pieces per MFMA -- the kernel is bound by the rate at which L2 / Infinity
+// Cache fill the LDS images (TCC hit rate 26 %, 36 GB/s per CU needed at the full MFMA rate), not by the matrix pipe.
+template <typename T, int NWR>
+__global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
     unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv) {
     static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
     constexpr int TH = 8;
-    constexpr int PB = 128;                     // bytes per pixel: 64 bf16 channels
+    constexpr int NT = 128 * NWR;               // threads
+    constexpr int PB = 128;                     // x bytes per pixel: 64 bf16 channels
+    constexpr int DPB = 64 * NWR;               // dy bytes per pixel: 32 * NWR bf16 channels
+    constexpr int DU = DPB / 16;                // 16-byte units per dy pixel (8 / 16)
     constexpr int XPIX = (TH + 2) * HALO_W;     // 180
     constexpr int DPIX = TH * TILE;             // 128
-    constexpr int XUNITS = XPIX * 8, DUNITS = DPIX * 8;      // 16-byte units
-    constexpr int XBYTES = XPIX * PB, STAGE = (XPIX + DPIX) * PB;   // 23040, 39424
+    constexpr int XUNITS = XPIX * 8;            // 16-byte units of the x image
+    constexpr int XR = (XUNITS + NT - 1) / NT;  // DMA rounds: 6 (256 threads) / 3 (512 threads)
+    constexpr int DR = DPIX * DU / NT;          // 4
+    // LDS stage = x halo image (6 DMA rounds of 256 threads x 16 B, the tail of the sixth is padding) + dy image (4 rounds):
+    // every thread issues exactly 10 pieces per tile, so that the hand-placed vmcnt waits count the same on every wave
+    constexpr int RB = NT * 16;                 // bytes per DMA round
+    constexpr int XBYTES = XR * RB, STAGE = XBYTES + DR * RB;       // 24576 + 16384 (NWR 2: 2 stages x 2 workgroups = all 160 KiB) / 24576 + 32768
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-    typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;     // wr: 32-row co block (0 .. NWR-1), wc: 32-column ci block
     const int Cin = C0 + C1;
     const int nci = Cin / 64;
     const int cot = blockIdx.y / nci, cit = blockIdx.y - cot * nci;
-    const int co0 = cot * 64, ci0 = cit * 64;
+    const int co0 = cot * (32 * NWR), ci0 = cit * 64;
     const T* xsrc; int ldx;
     int xleft;                                   // channels of this slab that exist in memory (narrow tensors)
     if (ci0 < C0) { xsrc = x0 + ci0; ldx = ld0; xleft = C0v - ci0; } else { xsrc = x1 + (ci0 - C0); ldx = ld1; xleft = C1v - (ci0 - C0); }
     const int dleft = Coutv - co0;
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc, 0, (int)x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)dy_bytes, 0x00020000);
+    const u32x4 rsx = uh_desc_words(xsrc, x_bytes);
+    const u32x4 rsd = uh_desc_words(dy + co0, dy_bytes);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     const int ntile = B * tilesX * tilesY;
     const int split = blockIdx.x;
@@ -1971,20 +1983,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
 
     // per-thread DMA geometry that does not depend on the tile: halo coordinates of each 16-byte unit and its byte
     // offset relative to the tile's top-left halo pixel (tile-dependent part is one scalar base + 4 range checks)
-    int xg[6], xo[6], dg[4], dof[4];
+    int xg[XR], xo[XR], dg[DR], dof[DR];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int p = tid + k * 256;
+    for (int k = 0; k < XR; ++k) {
+        const int p = tid + k * NT;
         const int q = p >> 3;
         const int hy = q / HALO_W, hx = q - hy * HALO_W;
         const int u = (p & 7) ^ (((hx >> 1) & 1) << 2);          // swizzle by halo COLUMN: row independent
         xg[k] = (p < XUNITS && u * 8 < xleft) ? ((hy << 8) | hx) : -1;       // units beyond the valid channels read as zeros
         xo[k] = (hy * W + hx) * ldx * 2 + u * 16;
     }
+    // dy image [pixel][DPB]: the 64-byte groups of a pixel row are XOR-ed with the column so that the 4 consecutive pixels
+    // of a transposed read hit 4 distinct bank groups (128-byte pitch: bit 1 of the column flips the two groups; 256-byte
+    // pitch: the two low column bits permute the four groups)
+    auto dswz = [&](int col) -> int { return NWR == 2 ? (((col >> 1) & 1) << 2) : ((col & 3) << 2); };     // in 16-byte units
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p = tid + k * 256;
-        const int q = p >> 3, u = (p & 7) ^ (((q >> 1) & 1) << 2);
+    for (int k = 0; k < DR; ++k) {
+        const int p = tid + k * NT;
+        const int q = p / DU, u = (p % DU) ^ dswz(q & 15);
         dg[k] = (u * 8 < dleft) ? (((q >> 4) << 8) | (q & 15)) : -1;
         dof[k] = ((q >> 4) * W + (q & 15)) * lddy * 2 + u * 16;
     }
@@ -1996,21 +2012,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         const int y0 = tyt * TH, x0p = txt * TILE;
         const int xbase = ((b * H + y0 - 1) * W + x0p - 1) * ldx * 2;     // may be "negative": only used when in range
         const int dbase = ((b * H + y0) * W + x0p) * lddy * 2;
-        unsigned char* xb = lds + bufi * STAGE + wave * 1024;
-        unsigned char* db = xb + XBYTES;
+        const unsigned xb = lds_base + bufi * STAGE + wave * 1024;
+        const unsigned db = xb + XBYTES;
+        // the 10 x 18 halo inside the image and the 8 x 16 dy tile complete: no per-piece range tests (wave-uniform)
+        const bool inside = y0 >= 1 && y0 + TH + 1 <= H && x0p >= 1 && x0p + TILE + 1 <= W;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int gy = y0 - 1 + (xg[k] >> 8), gx = x0p - 1 + (xg[k] & 255);
-            const bool ok = xg[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            unsigned voff = ok ? (unsigned)(xbase + xo[k]) : OOB_OFFSET;
-            if (k < 5 || tid + k * 256 < XUNITS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xb + k * 4096), 16, voff, 0, 0, 0);
+        for (int k = 0; k < XR; ++k) {
+            bool ok = xg[k] >= 0;                     // (slots past the halo image / past the stored channels: out of range)
+            if (!inside) {
+                const int gy = y0 - 1 + (xg[k] >> 8), gx = x0p - 1 + (xg[k] & 255);
+                ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
+            uh_dma16(rsx, xb + k * RB, ok ? (unsigned)(xbase + xo[k]) : OOB_OFFSET, 0);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int gy = y0 + (dg[k] >> 8), gx = x0p + (dg[k] & 255);
-            const bool ok = dg[k] >= 0 && gy < H && gx < W;
-            unsigned voff = ok ? (unsigned)(dbase + dof[k]) : OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(db + k * 4096), 16, voff, 0, 0, 0);
+        for (int k = 0; k < DR; ++k) {
+            bool ok = dg[k] >= 0;
+            if (!inside) {
+                const int gy = y0 + (dg[k] >> 8), gx = x0p + (dg[k] & 255);
+                ok = ok && gy < H && gx < W;
+            }
+            uh_dma16(rsd, db + k * RB, ok ? (unsigned)(dbase + dof[k]) : OOB_OFFSET, 0);
         }
     };
 
@@ -2030,7 +2052,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
     // Lane-constant LDS byte offsets of the two transposed reads of a fragment (pixels c, c+4 of a row); the halves
     // of a 128-byte pixel row are swapped by ((column >> 1) & 1), so 4 consecutive pixels hit 4 distinct bank groups.
     auto col_off = [&](int col, int cbyte) -> int { return col * PB + (cbyte ^ (((col >> 1) & 1) << 6)); };
-    const int d_lo = col_off(kh * 8 + rq, a_cbyte), d_hi = col_off(kh * 8 + rq + 4, a_cbyte);
+    auto dcol_off = [&](int col, int cbyte) -> int { return col * DPB + (cbyte ^ (dswz(col) << 4)); };
+    const int d_lo = dcol_off(kh * 8 + rq, a_cbyte), d_hi = dcol_off(kh * 8 + rq + 4, a_cbyte);
     int x_lo[3], x_hi[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -2038,12 +2061,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
         x_hi[s] = col_off(s + kh * 8 + rq + 4, b_cbyte);
     }
 
+    // The LDS-DMA is issued through inline asm (uh_dma16): the compiler does not see it, so it does not drain it in front
+    // of the tile's first ds_read (which it does for the builtin -- the DMA of tile t+1 then overlapped nothing); it is
+    // waited for by hand at the END of tile t, behind its 72 MFMAs per wave.
     if (t_begin < t_end) issue(t_begin, 0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     int bufi = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
 #ifndef UH_ABL_WG_NODMA
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #endif
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
@@ -2064,7 +2092,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
 #pragma unroll
         for (int hy = 0; hy < TH + 2; ++hy) {
             if (hy + 1 < TH + 2) {
-                dfr[hy + 1] = (hy + 1 < TH) ? tr_pair(ds + (hy + 1) * (TILE * PB), d_lo, d_hi) : zero8;
+                dfr[hy + 1] = (hy + 1 < TH) ? tr_pair(ds + (hy + 1) * (TILE * DPB), d_lo, d_hi) : zero8;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) xfr[hy + 1][s] = tr_pair(xs + (hy + 1) * (HALO_W * PB), x_lo[s], x_hi[s]);
             }
@@ -2076,7 +2104,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_v2(
                     if (hy - r >= 0 && hy - r < TH)
                         acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
-        __syncthreads();    // drains the DMA of tile+1 (vmcnt(0)) and frees this buffer
+        // the DMA of tile+1 has landed and every wave has finished reading this buffer
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #ifdef UH_ABL_WG_NOSTORE
@@ -2375,18 +2405,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_generic(const T* __restrict
 // =====================================================================================
 // host dispatch: wgrad
 // =====================================================================================
-struct WgradPlan { int kind; int nsplit; int tilesX, tilesY, ntile; };   // kind 0 = mfma, 1 = stem, 2 = generic
+struct WgradPlan { int kind; int nsplit; int tilesX, tilesY, ntile; int nwr; };   // kind 0 = mfma, 1 = stem, 2 = generic
 
+// wide = the bf16 LDS-DMA kernel with 128-row output-channel tiles (8 waves, one workgroup per CU) may be used
 template <typename T>
-static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned, bool wide) {
     constexpr int TH = WgradCfg<T>::TH;
     WgradPlan p;
+    p.nwr = 2;
     if (aligned && Cin % 64 == 0 && Cout % 64 == 0) {
         p.kind = 0;
         p.tilesX = (W + TILE - 1) / TILE; p.tilesY = (H + TH - 1) / TH;
         p.ntile = B * p.tilesX * p.tilesY;
-        int ctiles = (Cin / 64) * (Cout / 64);
-        int want = (512 + ctiles - 1) / ctiles;       // ~2 workgroups per CU in flight (LDS allows 2)
+        if (wide && sizeof(T) == 2 && Cout % 128 == 0) p.nwr = 4;
+        int ctiles = (Cin / 64) * (Cout / (32 * p.nwr));
+        int total = p.nwr == 4 ? 256 : 512;           // one 8-wave / two 4-wave workgroups per CU in flight (LDS)
+        int want = (total + ctiles - 1) / ctiles;
         p.nsplit = want < 1 ? 1 : (want > p.ntile ? p.ntile : want);
     } else if (Cin <= 4) {
         p.kind = 1;
@@ -2402,9 +2436,15 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned
 
 extern "C" size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt) {
     // alignment is unknown here: size for the slab paths (the generic path needs no workspace)
-    WgradPlan p = (dt == UH_BF16) ? wgrad_plan<bf16_t>(B, H, W, Cin, Cout, true) : wgrad_plan<float>(B, H, W, Cin, Cout, true);
+    WgradPlan p = (dt == UH_BF16) ? wgrad_plan<bf16_t>(B, H, W, Cin, Cout, true, false) : wgrad_plan<float>(B, H, W, Cin, Cout, true, false);
     if (p.kind == 2) return 16;
-    return (size_t)p.nsplit * Cout * 9 * Cin * sizeof(float) + 16;
+    size_t n = (size_t)p.nsplit * Cout * 9 * Cin * sizeof(float) + 16;
+    if (dt == UH_BF16) {      // the wide-tile plan of the LDS-DMA kernel may use a different split count: the larger of the two
+        WgradPlan q = wgrad_plan<bf16_t>(B, H, W, Cin, Cout, true, true);
+        size_t m = (size_t)q.nsplit * Cout * 9 * Cin * sizeof(float) + 16;
+        if (m > n) n = m;
+    }
+    return n;
 }
 
 template <typename T>
@@ -2417,7 +2457,14 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     const bool aligned = uh_aligned16(dy) && uh_aligned16(x0) && (C1 == 0 || uh_aligned16(x1)) && (lddy * ES) % 16 == 0 &&
                          (ld0 * ES) % 16 == 0 && (C1 == 0 || (ld1 * ES) % 16 == 0) && (C0 % 64 == 0);
-    WgradPlan p = wgrad_plan<T>(B, H, W, Cin, Cout, aligned);
+    // the bf16 LDS-DMA kernel (and with it the 128-row tile) needs every tensor addressable through a buffer descriptor
+    bool dma = false;
+    if constexpr (ES == 2) {
+        const int64_t npx_ = (int64_t)B * H * W;
+        const int64_t ldmax_ = ld0 > ld1 ? ld0 : ld1;
+        dma = npx_ * ldmax_ * 2 < (1ll << 31) - 4096 && npx_ * lddy * 2 < (1ll << 31) - 4096;
+    }
+    WgradPlan p = wgrad_plan<T>(B, H, W, Cin, Cout, aligned, dma && !narrow);
     if (p.kind == 1 && C1 != 0) p.kind = 2;
     if (narrow && p.kind != 0) {
         uh_set_error("uh_conv3x3_wgrad_narrow: needs the MFMA path (padded channel counts multiples of 64, 16-byte strides)");
@@ -2442,15 +2489,18 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     if (p.kind == 0) {
         const int64_t npx = (int64_t)B * H * W;
         const int64_t ldmax = ld0 > ld1 ? ld0 : ld1;
-        bool dma = false;
-        if constexpr (ES == 2) dma = npx * ldmax * 2 < (1ll << 31) - 4096 && npx * lddy * 2 < (1ll << 31) - 4096;
         if constexpr (ES == 2) {
             if (dma) {
                 // byte extents of the (sliced) source views as seen from their base pointers
                 unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
-                hipLaunchKernelGGL(conv3x3_wgrad_mfma_v2<T>, dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
-                                   lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb, C0v,
-                                   C1v, Coutv);
+                if (p.nwr == 4)
+                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
+                                       C0v, C1v, Coutv);
+                else
+                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 2>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
+                                       C0v, C1v, Coutv);
                 UH_CHECK_LAUNCH("conv3x3_wgrad_mfma_v2");
             }
         }
