@@ -2036,23 +2036,54 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         }
     };
 
+#ifndef UH_WGRAD_M16
+#define UH_WGRAD_M16 1      // 1: v_mfma_f32_16x16x32_bf16 (k = the 16 pixels of rows p and p+4), 0: v_mfma_f32_32x32x16_bf16 (k = one row)
+#endif
+    const int l16 = lane & 15;
+    const int rq = l16 >> 2, cp = l16 & 3;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#if UH_WGRAD_M16
+    // The chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md,
+    // DVFS give-back item 7), and this kernel runs at the power limit.  A wave's 32 x 32 (co, ci) block = 2 x 2 MFMA tiles;
+    // the contraction index of one MFMA = 32 pixels = the 16 columns of tile rows p and p + 4 (so that the x operand of
+    // tap row r is the row pair (p + r, p + r + 4): six pairs cover the ten halo rows).  Lane group g = lane >> 4 holds
+    // the 8 pixels (row p + 4 * (g >> 1), columns 8 * (g & 1) ...) of channel lane & 15 -- two transposed LDS reads.
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) acc[k][h][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g4 = lane >> 4;
+    const int rowsel = g4 >> 1, colh = g4 & 1;
+    const int a_cbyte = (wr * 32 + cp * 4) * 2;        // + 32 bytes for the second 16-channel half (bit 5: below the swizzle bits)
+    const int b_cbyte = (wc * 32 + cp * 4) * 2;
+#else
     f32x16 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
-
-    const int l16 = lane & 15;
     const int grp = (lane >> 4) & 1;
     const int kh = lane >> 5;
-    const int rq = l16 >> 2, cp = l16 & 3;
     const int a_cbyte = (wr * 32 + grp * 16 + cp * 4) * 2;
     const int b_cbyte = (wc * 32 + grp * 16 + cp * 4) * 2;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#endif
     // Lane-constant LDS byte offsets of the two transposed reads of a fragment (pixels c, c+4 of a row); the halves
     // of a 128-byte pixel row are swapped by ((column >> 1) & 1), so 4 consecutive pixels hit 4 distinct bank groups.
     auto col_off = [&](int col, int cbyte) -> int { return col * PB + (cbyte ^ (((col >> 1) & 1) << 6)); };
     auto dcol_off = [&](int col, int cbyte) -> int { return col * DPB + (cbyte ^ (dswz(col) << 4)); };
+#if UH_WGRAD_M16
+    const int d_lo = rowsel * 4 * (TILE * DPB) + dcol_off(colh * 8 + rq, a_cbyte);
+    const int d_hi = rowsel * 4 * (TILE * DPB) + dcol_off(colh * 8 + rq + 4, a_cbyte);
+    int x_lo[3], x_hi[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        x_lo[s] = rowsel * 4 * (HALO_W * PB) + col_off(s + colh * 8 + rq, b_cbyte);
+        x_hi[s] = rowsel * 4 * (HALO_W * PB) + col_off(s + colh * 8 + rq + 4, b_cbyte);
+    }
+#else
     const int d_lo = dcol_off(kh * 8 + rq, a_cbyte), d_hi = dcol_off(kh * 8 + rq + 4, a_cbyte);
     int x_lo[3], x_hi[3];
 #pragma unroll
@@ -2060,6 +2091,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         x_lo[s] = col_off(s + kh * 8 + rq, b_cbyte);
         x_hi[s] = col_off(s + kh * 8 + rq + 4, b_cbyte);
     }
+#endif
 
     // The LDS-DMA is issued through inline asm (uh_dma16): the compiler does not see it, so it does not drain it in front
     // of the tile's first ds_read (which it does for the builtin -- the DMA of tile t+1 then overlapped nothing); it is
@@ -2081,6 +2113,45 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
             s16x8 both = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             return __builtin_bit_cast(bf16x8, both);
         };
+#if UH_WGRAD_M16
+        // fully unrolled over the six x row pairs (a, a + 4): the fragments of pair a + 1 are fetched while pair a is
+        // multiplied; dy pair p = a - r meets tap row r
+        bf16x8 dfr[4][2];
+        bf16x8 xfr[6][3][2];
+        auto ld_x = [&](int a) {
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    xfr[a][sft][hh] = tr_pair(xs + a * (HALO_W * PB) + hh * 32, x_lo[sft], x_hi[sft]);
+        };
+        auto ld_d = [&](int pr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) dfr[pr][h] = tr_pair(ds + pr * (TILE * DPB) + h * 32, d_lo, d_hi);
+        };
+        ld_d(0);
+        ld_x(0);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            if (a + 1 < 6) ld_x(a + 1);
+            if (a + 1 < 4) ld_d(a + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int pr = a - r;
+                if (pr >= 0 && pr < 4) {
+#pragma unroll
+                    for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh)
+                                acc[r * 3 + sft][h][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[pr][h], xfr[a][sft][hh],
+                                                                                                 acc[r * 3 + sft][h][hh], 0, 0, 0);
+                }
+            }
+        }
+#else
         const bf16x8 zero8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         // fully unrolled over the 10 halo rows: row addresses are immediates, the dy fragments rotate by renaming,
         // and the fragments of row hy+1 are fetched while row hy is multiplied
@@ -2104,17 +2175,28 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
                     if (hy - r >= 0 && hy - r < TH)
                         acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
+#endif
         // the DMA of tile+1 has landed and every wave has finished reading this buffer
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
 
-#ifdef UH_ABL_WG_NOSTORE
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) asm volatile("" :: "v"(acc[tap]));
-    return;
-#endif
     float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
+#if UH_WGRAD_M16
+    // acc[tap][h][hh][j] = dW[co0 + wr*32 + h*16 + (lane >> 4)*4 + j][tap][ci0 + wc*32 + hh*16 + (lane & 15)]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = co0 + wr * 32 + h * 16 + (lane >> 4) * 4 + j;
+                    const int ci = ci0 + wc * 32 + hh * 16 + (lane & 15);
+                    slab[((int64_t)co * 9 + tap) * Cin + ci] = acc[tap][h][hh][j];
+                }
+#else
     const int ci = ci0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -2123,6 +2205,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
             int co = co0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
             slab[((int64_t)co * 9 + tap) * Cin + ci] = acc[tap][reg];
         }
+#endif
 }
 
 __global__ void slab_reduce_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nsplit) {
