@@ -538,8 +538,12 @@ __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }
 // one on this chip: x = xh + xl and w = wh + wl with bf16 halves (filters pre-split by uh_pack_w3x3, pixels split in
 // registers as their fragment arrives), and  w*x ~= wh*xh + wh*xl + wl*xh  (the dropped wl*xl term and the second
 // roundings are ~2^-17 relative: 1e-5, against a 1e-3 parity bar), accumulated in fp32 by v_mfma_f32_16x16x16_bf16.
-template <typename T, int NBW, bool SPLIT = false>
-__global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
+// WRES (bf16, NBW = 1, exactly two K-chunks = 64 input channels): the wave's whole filter slice (18 fragments = 72 VGPRs)
+// is loaded ONCE and stays in registers for every tile of the persistent workgroup.  The 64 -> 64 layers at 512 x 512 have
+// only 2 chunks per tile, so every 16x16 tile used to re-read the whole 74 KB filter through L1 (590 MB per launch, more
+// than the activations; TA 82 % busy): with it resident the main loop's only vector-memory traffic is the halo DMA.
+template <typename T, int NBW, bool SPLIT = false, bool WRES = false>
+__global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     int bufi = 0;
     // one column shift: rolling window over the 18 halo rows, row k+1 is fetched from LDS while output row k-2 is multiplied
     f32x4 acc[16][NBW];
-    auto mma_shift = [&](const unsigned char* buf, int sft, WFrag (&wv)[3][NBW]) {
+    auto mma_shift = [&](const unsigned char* buf, int sft, auto&& wget) {       // wget(r, n): filter fragment of row tap r, MFMA n
         u32x4 xf[18];
         // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
         const unsigned char* xcol = buf + (lx + sft) * 64 + ((kg ^ halo_swz(lx + sft)) << 4);
@@ -792,17 +796,17 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 for (int n = 0; n < NBW; ++n) {
                     if constexpr (ES == 2) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wv[r][n].v), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, wget(r, n).v), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
                     } else if constexpr (SPLIT) {
-                        const s16x4 wh = __builtin_bit_cast(s16x4, wv[r][n].hi);
-                        const s16x4 wlo = __builtin_bit_cast(s16x4, wv[r][n].lo);
+                        const s16x4 wh = __builtin_bit_cast(s16x4, wget(r, n).hi);
+                        const s16x4 wlo = __builtin_bit_cast(s16x4, wget(r, n).lo);
                         const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{xf[i + r][0], xf[i + r][1]});
                         const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xf[i + r][2], xf[i + r][3]});
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[i][n], 0, 0, 0);
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xlo, acc[i][n], 0, 0, 0);
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[i][n], 0, 0, 0);
                     } else {
-                        f32x4 a = __builtin_bit_cast(f32x4, wv[r][n].v);
+                        f32x4 a = __builtin_bit_cast(f32x4, wget(r, n).v);
                         f32x4 bb = __builtin_bit_cast(f32x4, xf[i + r]);
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq)
@@ -813,9 +817,24 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    auto wsel = [&](WFrag (&wv)[3][NBW]) { return [&wv](int r, int n) -> const WFrag& { return wv[r][n]; }; };
+    // WRES: the resident filter, [chunk][tap][n]
+    WFrag wres[WRES ? 2 : 1][WRES ? 9 : 1][NBW];
     dma_tile(tile);
     dma_chunk(chunk_of(0), 0, true);
-    load_w(wA, chunk_of(0), 0);
+    if constexpr (WRES) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    wres[c][t][n].v = u32x4{0u, 0u, 0u, 0u};
+                    wfrag_async(wres[c][t][n], (int64_t)c * CK + n * wnb_stride + (int64_t)t * Cin, n, t, c);
+                }
+    } else {
+        load_w(wA, chunk_of(0), 0);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
@@ -826,6 +845,26 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
 #pragma unroll
             for (int n = 0; n < NBW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (WRES) {
+            // two chunks, filter in registers: the only vector-memory traffic is the halo DMA of what follows
+#pragma unroll
+            for (int v = 0; v < 2; ++v, bufi ^= 1) {
+                const unsigned char* buf = lds + bufi * HALO2_STRIDE;
+                mma_shift(buf, 0, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 0][n]; });
+                if (v == 0) {
+                    dma_chunk(1, bufi ^ 1, true);
+                } else {
+                    const bool more = next_tile < ntile;
+                    if (more) dma_tile(next_tile);
+                    dma_chunk(0, bufi ^ 1, more);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_shift(buf, 1, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 1][n]; });
+                mma_shift(buf, 2, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 2][n]; });
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll 1
         for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
             const int cur_c = chunk_of(v);
@@ -833,7 +872,7 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
             const unsigned char* buf = lds + bufi * HALO2_STRIDE;
             load_w(wB, cur_c, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma_shift(buf, 0, wA);
+            mma_shift(buf, 0, wsel(wA));
             load_w(wC, cur_c, 2);
             // the halo tile of what follows chunk v: the tile's next chunk, else chunk 0 of the workgroup's next tile, else
             // nothing (six out-of-range pieces keep the instruction count of the waits below)
@@ -845,13 +884,14 @@ __global__ __launch_bounds__(256, (NBW == 1 ? 3 : 2)) void conv3x3_fwd_mfma_v2(
                 dma_chunk(chunk_of(0), bufi ^ 1, more);
             }
             UH_WAIT_VM(NWLOAD + NLOAD);               // WB landed (WC and the DMA stay in flight)
-            mma_shift(buf, 1, wB);
+            mma_shift(buf, 1, wsel(wB));
             load_w(wA, next_c, 0);
             UH_WAIT_VM(NLOAD + NWLOAD);               // WC landed (the DMA and WA' stay in flight)
-            mma_shift(buf, 2, wC);
+            mma_shift(buf, 2, wsel(wC));
             // DMA and WA' landed; every wave has finished reading this buffer
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 
 #ifdef UH_ABL_NOEPI
@@ -1489,6 +1529,12 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                                            w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
+                                       C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
+            } else if (ES == 2 && !split && !narrow && C0 + C1 == 2 * CK && !getenv("UH_NO_WRES")) {
+                // 64 input channels: the filter stays in registers (2 workgroups per CU: 72 more VGPRs)
+                int slabs = Cout / 64, gx = lanes_for(2, slabs);
+                if constexpr (ES == 2)
+                    hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                        C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
             } else {
                 int slabs = Cout / 64, gx = lanes_for(3, slabs);
