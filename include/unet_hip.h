@@ -154,6 +154,42 @@ int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int ldy,
                          const float* partials, int nblk, float* dgamma, float* dbeta,
                          void* dy, int lddy, int64_t npix, int64_t n_total, int C, int dt, uh_stream stream);
 
+/* ---- BatchNorm + ReLU fused with its consumer (csrc/bn_fused.hip) ---------------------------
+ * "pool tail": the second conv of an encoder DoubleConv (unet_parts.py:18-20), whose activation is the skip connection
+ * AND the input of nn.MaxPool2d(2) (unet_parts.py:32; unet_model.py:28-32).  uh_bn_relu_pool_ok: H, W even, C a multiple
+ * of 16 bytes.  apply: z = relu(bn(y)) [B,H,W,C] and pooled [B,H/2,W/2,C] in one pass over y.  The backward passes
+ * replace uh_maxpool2_bwd + uh_bn_relu_bwd_reduce / _apply: dz = dskip (may be NULL) + route(dpool) is rebuilt on the fly
+ * (never stored), bit-identical to what the unfused kernels compute; partials / nblk / dgamma / dbeta / n_total as in
+ * uh_bn_relu_bwd_reduce / uh_bn_relu_bwd_apply with npix = B*H*W. */
+int uh_bn_relu_pool_ok(int B, int H, int W, int C, int dt);
+int uh_bn_relu_pool_apply(const void* y, int ldy, const float* scale, const float* shift, void* z, int ldz,
+                          void* pooled, int ldp, int B, int H, int W, int C, int dt, uh_stream stream);
+int uh_bn_relu_pool_bwd_reduce(const void* dskip, int ldskip, const void* dpool, int lddp, const void* y, int ldy,
+                               const float* scale, const float* shift, const float* mean, const float* rstd,
+                               float* partials, int B, int H, int W, int C, int dt, uh_stream stream);
+int uh_bn_relu_pool_bwd_apply(const void* dskip, int ldskip, const void* dpool, int lddp, const void* y, int ldy,
+                              const float* scale, const float* shift, const float* mean, const float* rstd,
+                              const float* partials, int nblk, float* dgamma, float* dbeta, void* dy, int lddy,
+                              int B, int H, int W, int64_t n_total, int C, int dt, uh_stream stream);
+/* "head tail": the last DoubleConv's second conv, whose activation only feeds the 1x1 OutConv (unet_parts.py:103;
+ * unet_model.py:37).  uh_bn_relu_head_ok: C = 8 or 16 sixteen-byte channel groups (64 / 128 channels in bf16), n_classes
+ * <= 4.  fwd: logits[p][k] = head_b[k] + sum_c relu(bn(y))[p][c] * head_w[k][c] (fp32; the activation is rounded to the
+ * tensor dtype first, as if it had been stored) -- z is never written.  bwd_reduce: the BatchNorm partials of
+ * dz = dlogits . head_w AND the OutConv gradients dhead_w [ncls][C], dhead_b [ncls] (fp32, written); ws: scratch of
+ * uh_bn_relu_head_bwd_ws_bytes.  bwd_apply: as uh_bn_relu_bwd_apply with dz rebuilt from dlogits. */
+int uh_bn_relu_head_ok(int C, int ncls, int dt);
+int uh_bn_relu_head_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* head_w,
+                        const float* head_b, float* logits, int64_t npix, int C, int ncls, int dt, uh_stream stream);
+size_t uh_bn_relu_head_bwd_ws_bytes(int64_t npix, int C, int ncls);
+int uh_bn_relu_head_bwd_reduce(const float* dlogits, const float* head_w, const void* y, int ldy, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, float* partials,
+                               float* dhead_w, float* dhead_b, void* ws, size_t ws_bytes, int64_t npix, int C,
+                               int ncls, int dt, uh_stream stream);
+int uh_bn_relu_head_bwd_apply(const float* dlogits, const float* head_w, const void* y, int ldy, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, const float* partials,
+                              int nblk, float* dgamma, float* dbeta, void* dy, int lddy, int64_t npix,
+                              int64_t n_total, int C, int ncls, int dt, uh_stream stream);
+
 /* ---- nn.MaxPool2d(2)  (unet_parts.py:32) -------------------------------------------------- */
 int uh_maxpool2_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int dt,
                     uh_stream stream);

@@ -26,6 +26,8 @@ SHAPES = {
     "down1": (8, 256, 256, 64, 128),
     "down3": (8, 64, 64, 256, 512),
     "down4": (8, 32, 32, 512, 512),
+    "up1": (8, 64, 64, 1024, 256),
+    "up3": (8, 256, 256, 256, 64),
 }
 
 

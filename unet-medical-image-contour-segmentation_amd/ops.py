@@ -442,14 +442,35 @@ def _sync_bn_forward(coef, m2, n_local, Cout, g32, b32, running_mean, running_va
     return n_total
 
 
+# Fuse BatchNorm + ReLU of a DoubleConv's last conv with its consumer (csrc/bn_fused.hip) in training: TAIL_POOL where the
+# activation is skip connection + max-pool input (every encoder level), TAIL_HEAD where it only feeds the 1x1 OutConv.
+# False: the separate kernels (A/B measurements; the tests compare both).
+FUSE_TAILS = True
+TAIL_NONE, TAIL_POOL, TAIL_HEAD = 0, 1, 2
+
+
+def pool_tail_ok(x0: torch.Tensor, Cout: int) -> bool:
+    B, H, W, _ = x0.shape
+    return bool(FUSE_TAILS and LIB.query("uh_bn_relu_pool_ok", B, H, W, Cout, _dt(x0)))
+
+
+def head_tail_ok(x0: torch.Tensor, Cout: int, head_weight: torch.Tensor) -> bool:
+    return bool(FUSE_TAILS and head_weight.shape[1] == Cout and tuple(head_weight.shape[2:]) == (1, 1) and
+                LIB.query("uh_bn_relu_head_ok", Cout, head_weight.shape[0], _dt(x0)))
+
+
 class ConvBnReluFn(Function):
     """(nn.Conv2d(3x3, pad 1, no bias) -> nn.BatchNorm2d -> nn.ReLU) of unet_parts.py:15-17 / 18-20 as
     one autograd node.  Inputs: x0 (+ optional x1 = second half of the channel concat of
-    unet_parts.py:95, never materialised), the reference-layout parameters, BN buffers."""
+    unet_parts.py:95, never materialised), the reference-layout parameters, BN buffers.
+
+    `tail` (training only): TAIL_POOL -> returns (z, maxpool2(z)) (unet_parts.py:32 on top), the backward takes
+    (dskip, dpool) and never materialises their sum; TAIL_HEAD -> returns the fp32 logits of the 1x1 OutConv
+    (head_w [ncls,Cout,1,1], head_b; unet_parts.py:103) and z is never written."""
 
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
-                training: bool, momentum: float, eps: float):
+                training: bool, momentum: float, eps: float, tail: int = 0, head_w=None, head_b=None):
         _require_gpu(x0, "activation")
         x0 = dense_nhwc(x0)
         x1 = None if x1 is None else dense_nhwc(x1)
@@ -509,41 +530,116 @@ class ConvBnReluFn(Function):
                      pixel_ld(x1) if x1 is not None else 0, wf.data_ptr(), z.data_ptr(), Cout, Cout, scale.data_ptr(),
                      shift.data_ptr(), B, H, W, cdt | (UH_WFRAG if frag_f else 0), _stream())
             ctx.training = False
+            if tail != TAIL_NONE:
+                raise RuntimeError("ConvBnReluFn: fused tails are a training-mode path")
             return z
-        z = torch.empty_like(y)
-        LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
-                 n, Cout, _dt(y), _stream())
-        ctx.save_for_backward(x0, x1, y, coef, wd, weight)
         ctx.bn_params = (gamma, beta)
         ctx.training = training
         ctx.dims = (B, H, W, C0, C1, Cout)
         ctx.n_total = n_total
         ctx.sync_bn = SYNC_BN if n_total != n else None
+        ctx.tail = tail
+        if tail == TAIL_HEAD:
+            ncls = head_w.shape[0]
+            hw2 = head_w.reshape(ncls, Cout).contiguous().float()
+            hb2 = head_b.contiguous().float()
+            logits = torch.empty((B, H, W, ncls), dtype=torch.float32, device=dev)
+            LIB.call("uh_bn_relu_head_fwd", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), hw2.data_ptr(),
+                     hb2.data_ptr(), logits.data_ptr(), n, Cout, ncls, _dt(y), _stream())
+            ctx.save_for_backward(x0, x1, y, coef, wd, weight, hw2)
+            ctx.head_params = (head_w, head_b)
+            return logits
+        z = torch.empty_like(y)
+        if tail == TAIL_POOL:
+            pooled = torch.empty((B, H // 2, W // 2, Cout), dtype=y.dtype, device=dev)
+            LIB.call("uh_bn_relu_pool_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
+                     pooled.data_ptr(), Cout, B, H, W, Cout, _dt(y), _stream())
+            ctx.save_for_backward(x0, x1, y, coef, wd, weight)
+            ctx.set_materialize_grads(False)
+            return z, pooled
+        LIB.call("uh_bn_relu_apply", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), Cout,
+                 n, Cout, _dt(y), _stream())
+        ctx.save_for_backward(x0, x1, y, coef, wd, weight)
         return z
 
     @staticmethod
-    def backward(ctx, dz):
-        x0, x1, y, coef, wd, weight = ctx.saved_tensors
+    def backward(ctx, *grads):
+        tail = ctx.tail if ctx.training else TAIL_NONE
+        hw2 = None
+        if tail == TAIL_HEAD:
+            x0, x1, y, coef, wd, weight, hw2 = ctx.saved_tensors
+        else:
+            x0, x1, y, coef, wd, weight = ctx.saved_tensors
         B, H, W, C0, C1, Cout = ctx.dims
         if not ctx.training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the train path")
         Cin = C0 + C1
         n = B * H * W
         dev = y.device
-        dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
         scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
         dt = _dt(y)
         nblk = LIB.query("uh_bn_bwd_nblk", n, Cout)
         partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
-        LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
-                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
+        bn_args = (y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+        dhead = (None, None)
+        # The gradient of z: a tensor (no tail), dlogits . head_w (head tail) or dskip + route(dpool) (pool tail) -- the
+        # last two are rebuilt inside both BatchNorm passes instead of being stored.  `reduce()` writes the per-block
+        # sums, `apply(...)` finishes (or is handed) the per-channel sums and writes dy.
+        if tail == TAIL_HEAD:
+            dl = grads[0].float().contiguous()
+            ncls = hw2.shape[0]
+            head_w, head_b = ctx.head_params
+            (dwb, cb_hw), (dbb, cb_hb) = _grad_buffer(head_w), _grad_buffer(head_b)
+            direct = cb_hw is not None and cb_hb is not None and dwb.stride(0) == Cout and dwb.stride(1) == 1 and \
+                dbb.is_contiguous() and dwb.dtype == torch.float32 and dbb.dtype == torch.float32
+            dhw = dwb if direct else torch.empty((ncls, Cout), dtype=torch.float32, device=dev)
+            dhb = dbb if direct else torch.empty(ncls, dtype=torch.float32, device=dev)
+            nbytes = LIB.query("uh_bn_relu_head_bwd_ws_bytes", n, Cout, ncls)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+            def reduce():
+                LIB.call("uh_bn_relu_head_bwd_reduce", dl.data_ptr(), hw2.data_ptr(), *bn_args, partials.data_ptr(),
+                         dhw.data_ptr(), dhb.data_ptr(), ws.data_ptr(), nbytes, n, Cout, ncls, dt, _stream())
+                if direct:
+                    cb_hw()
+                    cb_hb()
+
+            def apply(part_ptr, nb, dg_ptr, db_ptr, n_total):
+                LIB.call("uh_bn_relu_head_bwd_apply", dl.data_ptr(), hw2.data_ptr(), *bn_args, part_ptr, nb, dg_ptr, db_ptr,
+                         dy.data_ptr(), Cout, n, n_total, Cout, ncls, dt, _stream())
+            dhead = (None, None) if direct else (dhw.view(head_w.shape), dhb)
+        elif tail == TAIL_POOL and grads[1] is not None:
+            dskip, dpool = grads
+            dpool = dense_nhwc(dpool if dpool.dtype == y.dtype else dpool.to(y.dtype))
+            if dskip is not None:
+                dskip = dense_nhwc(dskip if dskip.dtype == y.dtype else dskip.to(y.dtype))
+            sk = (_p(dskip), 0 if dskip is None else pixel_ld(dskip), dpool.data_ptr(), pixel_ld(dpool))
+
+            def reduce():
+                LIB.call("uh_bn_relu_pool_bwd_reduce", *sk, *bn_args, partials.data_ptr(), B, H, W, Cout, dt, _stream())
+
+            def apply(part_ptr, nb, dg_ptr, db_ptr, n_total):
+                LIB.call("uh_bn_relu_pool_bwd_apply", *sk, *bn_args, part_ptr, nb, dg_ptr, db_ptr, dy.data_ptr(), Cout,
+                         B, H, W, n_total, Cout, dt, _stream())
+        else:
+            dz = grads[0]
+            if dz is None:          # pool tail whose outputs were both unused
+                return (None,) * 14
+            dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
+
+            def reduce():
+                LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), *bn_args, partials.data_ptr(), n, Cout, dt,
+                         _stream())
+
+            def apply(part_ptr, nb, dg_ptr, db_ptr, n_total):
+                LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), *bn_args, part_ptr, nb, dg_ptr, db_ptr,
+                         dy.data_ptr(), Cout, n, n_total, Cout, dt, _stream())
+        reduce()
         gamma_p, beta_p = ctx.bn_params
         (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
         dy = torch.empty_like(y)
         if ctx.sync_bn is None:
-            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
-                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), nblk, dgamma.data_ptr(),
-                     dbeta.data_ptr(), dy.data_ptr(), Cout, n, 0, Cout, dt, _stream())
+            apply(partials.data_ptr(), nblk, dgamma.data_ptr(), dbeta.data_ptr(), 0)
         else:
             # SyncBN: the parameter gradients stay LOCAL sums (the gradient all-reduce SUMS them like every other
             # gradient: the loss is already normalised by the global batch); the dx formula needs the GLOBAL sums and the
@@ -552,9 +648,7 @@ class ConvBnReluFn(Function):
             LIB.call("uh_bn_bwd_finalize", partials.data_ptr(), nblk, Cout, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
             glob = torch.cat([dgamma.reshape(-1), dbeta.reshape(-1)])
             dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.sync_bn[0])
-            LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
-                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, 0, glob[:Cout].data_ptr(),
-                     glob[Cout:].data_ptr(), dy.data_ptr(), Cout, n, ctx.n_total, Cout, dt, _stream())
+            apply(None, 0, glob[:Cout].data_ptr(), glob[Cout:].data_ptr(), ctx.n_total)
         # backward-data first: it is the only consumer on the critical path (the next layer's BatchNorm backward waits
         # for it).  Backward-weights then goes to the side stream BEHIND it, so that it runs beside the HBM-bound
         # kernels of the layers that follow (BatchNorm backward, pool / upsample backward) instead of beside this
@@ -597,7 +691,7 @@ class ConvBnReluFn(Function):
         if cb_b is not None:
             cb_b()
             dbeta = None
-        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None
+        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1]
 
 
 # ----------------------------------------------------------------------------- small-width conv + BN + ReLU

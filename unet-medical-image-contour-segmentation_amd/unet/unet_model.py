@@ -41,14 +41,22 @@ class UNetDepth(nn.Module):
         self.compute_dtype = torch.float32
 
     def forward_nhwc(self, x):
+        # Every encoder DoubleConv hands its output to the max-pool of the next Down AND to the skip connection, the last
+        # decoder DoubleConv hands its output to OutConv: the blocks are told their consumer so that BatchNorm + ReLU and
+        # the consumer run as one kernel where csrc/bn_fused.hip covers the shape (unet_model.py:28-38 is the same graph).
         skips = []
-        h = self.inc.nhwc(x)
+        skip, pooled = self.inc.nhwc(x, tail="pool")
+        skips.append(skip)
         for k in range(1, self.depth + 1):
-            skip, h = getattr(self, f"down{k}").nhwc_with_skip(h)
-            skips.append(skip)
+            block = getattr(self, f"down{k}").maxpool_conv[1]
+            if k < self.depth:
+                skip, pooled = block.nhwc(pooled, tail="pool")
+                skips.append(skip)
+            else:
+                h = block.nhwc(pooled)
         for j in range(1, self.depth + 1):
-            h = getattr(self, f"up{j}").nhwc(h, skips[self.depth - j])
-        return self.outc.nhwc(h)
+            h = getattr(self, f"up{j}").nhwc(h, skips[self.depth - j], tail=self.outc if j == self.depth else None)
+        return h
 
     def forward(self, x):
         dt = ops.compute_dtype(self.compute_dtype)

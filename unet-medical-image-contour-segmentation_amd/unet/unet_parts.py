@@ -35,10 +35,21 @@ def _pad_c(t, cpad: int):
     return t if c == cpad else torch.nn.functional.pad(t, (0, cpad - c))
 
 
+def _finish_tail(z, tail):
+    """The consumer of a DoubleConv's output as separate kernels: None -> z; "pool" -> (z as skip, maxpool2(z));
+    an OutConv -> its logits."""
+    if tail is None:
+        return z
+    if tail == "pool":
+        return ops.PoolSplitFn.apply(z)
+    return tail.nhwc(z)
+
+
 def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, keep_padded: bool = False,
-                  x0_channels: int = None):
-    """One (conv3x3 -> BatchNorm -> ReLU) layer.  Layers whose channel counts are not multiples of 64 (the small-width
-    UNet_S / UNet_T of unet_model.py:52-126) are computed as the next larger 64-aligned layer with zero filters / unit
+                  x0_channels: int = None, tail=None):
+    """One (conv3x3 -> BatchNorm -> ReLU) layer, plus its consumer `tail` (see _finish_tail) -- fused into the BatchNorm
+    kernels where csrc/bn_fused.hip covers the shape (training, 64-aligned layers), separate kernels otherwise.
+    Layers whose channel counts are not multiples of 64 (the small-width UNet_S / UNet_T of unet_model.py:52-126) are computed as the next larger 64-aligned layer with zero filters / unit
     gamma in the padding, so that they use the same MFMA kernels as the full-width UNet instead of the generic scalar
     kernels.  Default (ops.NARROW_IO): the tensors themselves stay at their real channel count (ConvBnReluNarrowFn).
     Otherwise / for channel counts that are not 16-byte multiples: zero-padded 64-channel tensors -- padded input
@@ -56,17 +67,21 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
     Cp1 = _rup(C1) if C1 else 0
     Cop = _rup(Cout)
     if Cp0 == C0 and Cp1 == C1 and Cop == Cout and x0_channels is None:
-        z = ops.ConvBnReluFn.apply(x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   bn.num_batches_tracked, training, momentum, bn.eps)
-        return z
+        args = (x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training, momentum,
+                bn.eps)
+        if training and tail == "pool" and ops.pool_tail_ok(x0, Cout):
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None)
+        if training and isinstance(tail, OutConv) and ops.head_tail_ok(x0, Cout, tail.conv.weight):
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias)
+        return _finish_tail(ops.ConvBnReluFn.apply(*args), tail)
     if ops.NARROW_IO and x0_channels is None:
         # tensors keep their real channel count in HBM, only the arithmetic is padded (ops.ConvBnReluNarrowFn); the
         # 1- / 3-channel image is widened to one 16-byte piece so that it can be fetched like any other activation
         vec = 16 // x0.element_size()
         x0n = _pad_c(x0, (C0 + vec - 1) // vec * vec)
         if ops.narrow_ok(x0n, x1, Cout):
-            return ops.ConvBnReluNarrowFn.apply(x0n, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                bn.num_batches_tracked, training, momentum, bn.eps, C0)
+            return _finish_tail(ops.ConvBnReluNarrowFn.apply(x0n, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                             bn.num_batches_tracked, training, momentum, bn.eps, C0), tail)
     x0p = x0 if x0_channels is not None else _pad_c(x0, Cp0)
     x1p = None if x1 is None else _pad_c(x1, Cp1)
     # filter [Cout, C0 + C1, 3, 3] -> [Cop, Cp0 + Cp1, 3, 3]: each source's channel block is padded separately
@@ -85,7 +100,7 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
         with torch.no_grad():
             bn.running_mean.copy_(rm[:Cout])
             bn.running_var.copy_(rv[:Cout])
-    return zp if keep_padded else zp[..., :Cout]
+    return _finish_tail(zp if keep_padded else zp[..., :Cout], tail)
 
 
 class DoubleConv(nn.Module):
@@ -105,11 +120,14 @@ class DoubleConv(nn.Module):
         ]
         self.double_conv = nn.Sequential(*layers)
 
-    def nhwc(self, x0, x1=None):
+    def nhwc(self, x0, x1=None, tail=None):
+        """`tail`: what consumes the block's output -- None (returns it), "pool" (returns (output, maxpool2(output)):
+        unet_parts.py:32 of the next Down) or the network's OutConv (returns its logits)."""
         seq = self.double_conv
         mid = seq[0].weight.shape[0]
         h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training, keep_padded=True)
-        return _conv_bn_relu(h, None, seq[3], seq[4], self.training, x0_channels=mid if h.shape[-1] != mid else None)
+        return _conv_bn_relu(h, None, seq[3], seq[4], self.training, x0_channels=mid if h.shape[-1] != mid else None,
+                             tail=tail)
 
     def forward(self, x):
         return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
@@ -152,13 +170,13 @@ class Up(nn.Module):
         self.use_attention = False
         self.attention = nn.Identity()
 
-    def nhwc(self, x1, x2):
+    def nhwc(self, x1, x2, tail=None):
         Ho, Wo = x2.shape[1], x2.shape[2]
         if self.bilinear:
             u = ops.UpsampleBilinearPadFn.apply(x1, Ho, Wo)
         else:
             u = ops.ConvTranspose2x2PadFn.apply(x1, self.up.weight, self.up.bias, Ho, Wo)
-        return self.conv.nhwc(x2, u)          # channel order [skip, up] as unet_parts.py:95
+        return self.conv.nhwc(x2, u, tail=tail)          # channel order [skip, up] as unet_parts.py:95
 
     def forward(self, x1, x2):
         dt = ops.compute_dtype(x1.dtype if x1.dtype == torch.bfloat16 else torch.float32)
