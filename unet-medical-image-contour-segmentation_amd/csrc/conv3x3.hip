@@ -820,6 +820,9 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     auto wsel = [&](WFrag (&wv)[3][NBW]) { return [&wv](int r, int n) -> const WFrag& { return wv[r][n]; }; };
     // WRES: the resident filter, [chunk][tap][n]
     WFrag wres[WRES ? 2 : 1][WRES ? 9 : 1][NBW];
+#ifdef UH_ABL_CLK      // timing-only: core clocks / 100 MHz ticks spent by workgroup 0 -> stats[0..1] (clobbers the statistics)
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     dma_tile(tile);
     dma_chunk(chunk_of(0), 0, true);
     if constexpr (WRES) {
@@ -939,7 +942,11 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             const int sbase = ((b * H + y0) * W) * ldy * ES;                   // row 0 of the tile, column 0
             if constexpr (PERM2) {
                 const int c0 = co_blk + ch(kg, 0, 0);
+#ifdef UH_ABL_OOBSTORE      // timing-only: every store is dropped by the descriptor's range check (profiles/README.md)
+                const bool inr = false;
+#else
                 const bool inr = gx < W && c0 < Coutv;
+#endif
                 const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -953,7 +960,11 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                 // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
                 const int c0 = co_blk + wave * 16 + (kg & 1) * 8;
                 const int rsel = kg >> 1;
+#ifdef UH_ABL_OOBSTORE
+                const bool inr = false;
+#else
                 const bool inr = gx < W && c0 < Coutv;
+#endif
                 const unsigned voff0 = (unsigned)((gx * ldy + c0) * ES + rsel * rbytes);
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
@@ -1059,6 +1070,16 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                     stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = fmaxf(a2 - a1 * a1 * inv_n, 0.f); // M2
                 }
         }
+#ifdef UH_ABL_CLK
+        if (tid == 0) {      // per workgroup: start / end stamps (100 MHz, low 24 bits), core clocks spent
+            float* o = stats + (int64_t)ntile * (2 * Cout + 1) + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;   // the slack behind the counts
+            o[0] = (float)(clk_r0 & 0xFFFFFFull);
+            o[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);
+            o[2] = (float)(__builtin_amdgcn_s_memtime() - clk_t0);
+            // XCC_ID (hwreg 20, low 4 bits) * 65536 + HW_ID (hwreg 4, low 16 bits: wave, simd, pipe, cu, sh, se)
+            o[3] = (float)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 65536u + __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4));
+        }
+#endif
         float* counts = stats + (int64_t)ntile * 2 * Cout;
         if (slab == 0) {
             if (tid == 0) counts[tile_lane] = n_run;
