@@ -59,8 +59,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank flow on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--no-side-stream", action="store_true",
-                    help="keep backward-weights on the launch stream (clean per-kernel durations under rocprofv3)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="backward-weights kernels on a stream of their own (measured 2-3 %% slower than one stream: DESIGN.md)")
+    ap.add_argument("--no-side-stream", action="store_true", help="(the default since round 2; accepted for old command lines)")
     return ap.parse_args()
 
 
@@ -178,7 +179,7 @@ def main():
         model = unet_amd.UNet(1, 1, bilinear=bilinear)
     model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
-    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=not args.no_side_stream, cc_loss=args.cc_loss,
+    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=args.side_stream and not args.no_side_stream, cc_loss=args.cc_loss,
                                    fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
     g = torch.Generator().manual_seed(1 + rank)
     strong = args.global_batch > 0

@@ -324,3 +324,25 @@ def test_two_backwards_before_step_are_refused():
     unet_amd.seg_loss(model(im.to(dev)), mk.to(dev), 1)["loss"].backward()
     with pytest.raises(RuntimeError, match="gradient accumulation"):
         unet_amd.seg_loss(model(im.to(dev)), mk.to(dev), 1)["loss"].backward()
+
+
+def test_side_stream_for_backward_weights_changes_nothing():
+    """TrainStepper(wgrad_stream=True) (opt-in since round 2: one stream measured faster) runs the same kernels in another
+    order of issue: parameters after three steps are bit-identical."""
+    import unet_amd
+    dev = _dev()
+    outs = []
+    for side in (False, True):
+        torch.manual_seed(5)
+        model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+        st = unet_amd.TrainStepper(model, lr=1e-4, amp=True, wgrad_stream=side)
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(2, 1, 128, 128, generator=g).to(dev)
+        t = (torch.rand(2, 128, 128, generator=g) > 0.5).long().to(dev)
+        for _ in range(3):
+            terms = st.step(x, t)
+        torch.cuda.synchronize()
+        outs.append((float(terms["loss"]), st.optimizer.flat_p.detach().clone()))
+        st.optimizer.close() if hasattr(st.optimizer, "close") else None
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])

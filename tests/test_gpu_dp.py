@@ -31,7 +31,8 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         torch.manual_seed(0)
         model = unet_amd.UNet_S(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
-        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=True)
+        # the opt-in side stream for backward-weights: its events gate the per-bucket all-reduce (dp.BucketedGradSync)
+        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=True, wgrad_stream=True)
         assert stepper.world == 2 and stepper.optimizer.sync is not None and len(stepper.optimizer.sync.buckets) >= 1
         g = torch.Generator().manual_seed(10 + rank)
         images = torch.rand(2, 1, 96, 96, generator=g).to(dev)

@@ -370,41 +370,46 @@ extern "C" int uh_bn_relu_bwd_reduce(const void* dz, int lddz, const void* y, in
     return UH_OK;
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    // block = 16 channels x 64 row lanes (C/16 blocks: even a 64-channel layer spreads over 4 CUs and every thread
-    // walks only nblk/64 rows); double: sum(dz) cancels heavily behind a BatchNorm
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 16 + cl;
+// 512 threads = 8 channels x 64 row lanes (C/8 blocks, every thread walks nblk/64 rows).  Two waves per SIMD at <= 72 VGPRs:
+// this kernel sits on the critical path of the backward pass between the two BatchNorm passes, and with 1024-thread blocks
+// (four waves per SIMD, 4 x 72 registers) it could not be placed on a CU while a backward-weights workgroup of the side
+// stream held half of the register file -- it waited 50-340 us for that kernel to END (kernel trace, profiles/README.md).
+constexpr int BWF_CH = 8, BWF_THREADS = 512;
+__global__ __launch_bounds__(BWF_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // double: sum(dz) cancels heavily behind a BatchNorm
+    __shared__ double red[2][BWF_THREADS / 64][BWF_CH];
+    const int cl = threadIdx.x % BWF_CH, sl = threadIdx.x / BWF_CH, wave = threadIdx.x >> 6;
+    constexpr int RL = BWF_THREADS / BWF_CH;          // 64 row lanes
+    const int c = blockIdx.x * BWF_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // batches of 8 rows: 16 independent loads in flight per thread, then the adds in row order
         int s = sl;
-        for (; s + 7 * 64 < nblk; s += 8 * 64) {
+        for (; s + 7 * RL < nblk; s += 8 * RL) {
             float va[8], vb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                va[i] = partials[((int64_t)(s + 64 * i) * 2 + 0) * C + c];
-                vb[i] = partials[((int64_t)(s + 64 * i) * 2 + 1) * C + c];
+                va[i] = partials[((int64_t)(s + RL * i) * 2 + 0) * C + c];
+                vb[i] = partials[((int64_t)(s + RL * i) * 2 + 1) * C + c];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) { a += (double)va[i]; b += (double)vb[i]; }
         }
-        for (; s < nblk; s += 64) {
+        for (; s < nblk; s += RL) {
             a += (double)partials[((int64_t)s * 2 + 0) * C + c];
             b += (double)partials[((int64_t)s * 2 + 1) * C + c];
         }
     }
-    // the four row lanes of a wave (lane bits 4,5), then the 16 waves through LDS
-    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-    if ((threadIdx.x & 63) < 16) { red[0][wave][cl] = a; red[1][wave][cl] = b; }
+    // the eight row lanes of a wave (lane bits 3..5), then the 8 waves through LDS
+#pragma unroll
+    for (int o = BWF_CH; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) < BWF_CH) { red[0][wave][cl] = a; red[1][wave][cl] = b; }
     __syncthreads();
-    if (threadIdx.x < 16 && c < C) {
+    if (threadIdx.x < BWF_CH && c < C) {
         double x = 0.0, y = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { x += red[0][k][cl]; y += red[1][k][cl]; }
+        for (int k = 0; k < BWF_THREADS / 64; ++k) { x += red[0][k][cl]; y += red[1][k][cl]; }
         dbeta[c] = (float)x;
         dgamma[c] = (float)y;
     }
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
 
 extern "C" int uh_bn_bwd_finalize(const float* partials, int nblk, int C, float* dgamma, float* dbeta, uh_stream stream) {
     UH_REQUIRE(partials && dgamma && dbeta && nblk > 0 && C > 0, "uh_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, nblk, C, dgamma,
-                       dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BWF_CH - 1) / BWF_CH), dim3(BWF_THREADS), 0, (hipStream_t)stream, partials, nblk, C,
+                       dgamma, dbeta);
     UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     return UH_OK;
 }
@@ -468,7 +473,7 @@ extern "C" int uh_bn_relu_bwd_apply(const void* dz, int lddz, const void* y, int
                "uh_bn_relu_bwd_apply: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     if (nblk > 0) {          // nblk == 0: dgamma / dbeta already hold the (possibly cross-rank) sums
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, nblk, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BWF_CH - 1) / BWF_CH), dim3(BWF_THREADS), 0, st, partials, nblk, C, dgamma, dbeta);
         UH_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     }
     float inv_n = (float)(1.0 / (double)(n_total > 0 ? n_total : npix));

@@ -1532,6 +1532,9 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             // persistent workgroups: 2 (NBW=2, VGPR-bound) or 3 (NBW=1) per CU, spread over the channel slabs; the
             // number of tile lanes is rounded to a multiple of 8 for the XCD-aware mapping inside the kernel
             auto lanes_for = [&](int per_cu, int slabs) {
+#ifdef UH_ABL_ONE_PER_CU      // timing-only: one workgroup per CU
+                per_cu = 1;
+#endif
                 int gx = (per_cu * 256 + slabs - 1) / slabs;
                 gx = (gx + 7) & ~7;
                 if (gx > ntile) gx = ntile;
@@ -2567,9 +2570,12 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, bool aligned
         p.kind = 0;
         p.tilesX = (W + TILE - 1) / TILE; p.tilesY = (H + TH - 1) / TH;
         p.ntile = B * p.tilesX * p.tilesY;
-        if (wide && sizeof(T) == 2 && Cout % 128 == 0) p.nwr = 4;
+        // UH_WGRAD_HALF_CU=1 (experiment): 4-wave workgroups, one per CU -- backward-weights then holds half of every CU and the
+        // kernels of the main stream can run beside it
+        static const bool half_cu = getenv("UH_WGRAD_HALF_CU") != nullptr;
+        if (wide && sizeof(T) == 2 && Cout % 128 == 0 && !half_cu) p.nwr = 4;
         int ctiles = (Cin / 64) * (Cout / (32 * p.nwr));
-        int total = p.nwr == 4 ? 256 : 512;           // one 8-wave / two 4-wave workgroups per CU in flight (LDS)
+        int total = (p.nwr == 4 || half_cu) ? 256 : 512;           // one 8-wave / two 4-wave workgroups per CU in flight (LDS)
         int want = (total + ctiles - 1) / ctiles;
         p.nsplit = want < 1 ? 1 : (want > p.ntile ? p.ntile : want);
     } else if (Cin <= 4) {

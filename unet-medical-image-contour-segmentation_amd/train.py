@@ -299,10 +299,16 @@ class TrainStepper:
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
                  gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
-                 wgrad_stream: bool = True, cc_loss: bool = False, sync_bn: bool = False, fp32_mode: str = "exact"):
+                 wgrad_stream: bool = False, cc_loss: bool = False, sync_bn: bool = False, fp32_mode: str = "exact"):
         self.model = model
+        # wgrad_stream: backward-weights kernels on a stream of their own.  Off by default: a kernel trace shows them
+        # overlapping with the BatchNorm / backward-data kernels of the launch stream as intended, and every kernel of
+        # the pair then runs about as much slower as the overlap saves (the chip is at its power limit either way) --
+        # the step is 2-3 % FASTER on one stream (DESIGN.md "Measured (round 2)").
         if wgrad_stream and ops.WGRAD_STREAM is None:
             ops.WGRAD_STREAM = torch.cuda.Stream()
+        elif not wgrad_stream:
+            ops.WGRAD_STREAM = None
         self.amp = amp
         self.check_nan = check_nan
         if fp32_mode not in ("exact", "bf16x3"):
