@@ -19,6 +19,15 @@ __global__ __launch_bounds__(256) void wk(u32x4* __restrict__ out, long npix, in
             if (MODE == 0) piece = (long)(wave * 8 + k) * 64 + lane;                       // 1 KiB contiguous per instruction
             else if (MODE == 1) { const int px = k * 32 + (lane >> 1); piece = (long)px * 8 + wave * 2 + (lane & 1); }   // 32 B per pixel
             else { const int px = k * 32 + (lane >> 2) + (wave & 1) * 16; piece = (long)px * 8 + (wave >> 1) * 4 + (lane & 3); }  // 64 B per pixel
+            if (MODE == 3) {
+                // the conv's real layout: tile t = (band of 16 image rows, column block of 16 pixels) of a [512 rows][512 px][128 B]
+                // image; a tile row is 2 KiB contiguous, tile rows are 64 KiB apart
+                const long img = t / 1024, tt = t % 1024, band = tt / 32, col = tt % 32;
+                const int px = k * 32 + (lane >> 1);                  // 32-byte pieces like mode 1
+                const int row = px >> 4, x = px & 15;
+                const long byte = ((img * 512 + band * 16 + row) * 512 + col * 16 + x) * 128 + wave * 32 + (lane & 1) * 16;
+                out[byte / 16] = v;
+            } else
             out[t * 2048 + piece] = v;
         }
         // a little dependent ALU work between tiles (keeps the store bursts apart like a main loop would)
@@ -33,8 +42,8 @@ int main(int argc, char** argv) {
     hipMalloc(&d, npix * 128);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int spin : {0, 2000, 8000}) {
-        for (int mode = 0; mode < 3; ++mode) {
+    for (int spin : {0}) {
+        for (int mode = 0; mode < 4; ++mode) {
             for (int grid : {512, 2048}) {
                 float best = 1e9;
                 for (int rep = 0; rep < 5; ++rep) {
@@ -42,7 +51,8 @@ int main(int argc, char** argv) {
                     for (int it = 0; it < 10; ++it) {
                         if (mode == 0) hipLaunchKernelGGL(wk<0>, dim3(grid), dim3(256), 0, 0, d, npix, spin);
                         else if (mode == 1) hipLaunchKernelGGL(wk<1>, dim3(grid), dim3(256), 0, 0, d, npix, spin);
-                        else hipLaunchKernelGGL(wk<2>, dim3(grid), dim3(256), 0, 0, d, npix, spin);
+                        else if (mode == 2) hipLaunchKernelGGL(wk<2>, dim3(grid), dim3(256), 0, 0, d, npix, spin);
+                        else hipLaunchKernelGGL(wk<3>, dim3(grid), dim3(256), 0, 0, d, npix, spin);
                     }
                     hipEventRecord(e1); hipEventSynchronize(e1);
                     float ms; hipEventElapsedTime(&ms, e0, e1);
