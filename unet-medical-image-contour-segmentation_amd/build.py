@@ -17,6 +17,9 @@ OBJ_DIR = os.path.join(CSRC, "build")
 SOURCES = ["uh_error.hip", "conv3x3.hip", "bn.hip", "bn_fused.hip", "pool_up.hip", "convt_1x1.hip", "convt_mfma.hip", "loss.hip", "optim.hip", "cc_loss.hip", "infer.hip", "post_process.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
+# sources whose kernels carry hand-counted waits around inline-asm loads: their device ISA is kept (-save-temps) and
+# linted after every compile (isa_lint.py: no spill inside the MFMA region, no touch of an in-flight destination)
+LINTED = {"conv3x3.hip": "conv3x3-hip-amdgcn-amd-amdhsa-gfx950.s"}
 
 
 def _hipcc() -> str:
@@ -45,7 +48,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            extra = ["-save-temps=obj"] if src in LINTED else []
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -57,9 +61,40 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
+    lint_isa(verbose)
     if force or jobs or _stale(LIB_PATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
+
+
+def lint_isa(verbose: bool = False) -> None:
+    """Check the ISA of the hand-scheduled kernels (see isa_lint.py); raises on a violation.  Runs on every build_library
+    call for which the ISA file exists (it is written next to the objects by the compile above)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_uh_isa_lint", os.path.join(PKG_DIR, "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    for src, isa in LINTED.items():
+        path = os.path.join(OBJ_DIR, isa)
+        if not os.path.exists(path):
+            continue                      # prebuilt objects without temps (the GPU box uses the shipped .so)
+        errs, report = lint.lint_asm(open(path).read())
+        stem = src.replace(".hip", "")
+        for f in os.listdir(OBJ_DIR):          # the other -save-temps by-products (13 MB) are of no use: keep the device ISA only
+            if f != isa and (f.startswith(stem + "-") or f.startswith(stem + ".hip-")):
+                os.remove(os.path.join(OBJ_DIR, f))
+        with open(os.path.join(OBJ_DIR, src.replace(".hip", ".isa_lint.json")), "w") as f:
+            import json
+            json.dump({"rocm": lint.rocm_version(), "validated_rocm": lint.VALIDATED_ROCM, "kernels": report,
+                       "violations": errs}, f, indent=1)
+        if lint.rocm_version() != lint.VALIDATED_ROCM:
+            print(f"WARNING: {src} was validated on ROCm {lint.VALIDATED_ROCM}, this is {lint.rocm_version()}: the hand-counted "
+                  "waits depend on hipcc's instruction selection -- run the parity tests before trusting this build", flush=True)
+        if errs:
+            os.remove(os.path.join(OBJ_DIR, src.replace(".hip", ".o")))       # never link a build that failed the lint
+            raise RuntimeError("ISA lint failed for " + src + ":\n  " + "\n  ".join(errs))
+        if verbose:
+            print(f"isa lint {src}: {len(report)} guarded kernels clean", flush=True)
 
 
 if __name__ == "__main__":

@@ -644,10 +644,6 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
 #pragma unroll
                 for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(rel0[k] + base);
                 if (tid + (NLOAD - 1) * 256 >= NPIECE) voff[NLOAD - 1] = OOB_OFFSET;
-#ifdef UH_ABL_DMACOAL    // timing-only: contiguous 1 KiB per wave instruction
-#pragma unroll
-                for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(base + (d_y0 * W) * 0 + tid * 16 + k * 4096 + ((d_y0 + 1) * W + d_x0) * 0);
-#endif
             } else {
                 // (the opaque copy of tid keeps the per-slot coordinates from being hoisted out of the tile loop into 12
                 // long-lived registers: the main loop runs at the register limit)
@@ -820,9 +816,6 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     auto wsel = [&](WFrag (&wv)[3][NBW]) { return [&wv](int r, int n) -> const WFrag& { return wv[r][n]; }; };
     // WRES: the resident filter, [chunk][tap][n]
     WFrag wres[WRES ? 2 : 1][WRES ? 9 : 1][NBW];
-#ifdef UH_ABL_CLK      // timing-only: core clocks / 100 MHz ticks spent by workgroup 0 -> stats[0..1] (clobbers the statistics)
-    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     dma_tile(tile);
     dma_chunk(chunk_of(0), 0, true);
     if constexpr (WRES) {
@@ -897,13 +890,6 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         }
         }
 
-#ifdef UH_ABL_NOEPI
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) asm volatile("" :: "v"(acc[i][n]));
-        continue;
-#endif
         // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_blk + ch(kg, n, j)]
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
@@ -942,11 +928,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             const int sbase = ((b * H + y0) * W) * ldy * ES;                   // row 0 of the tile, column 0
             if constexpr (PERM2) {
                 const int c0 = co_blk + ch(kg, 0, 0);
-#ifdef UH_ABL_OOBSTORE      // timing-only: every store is dropped by the descriptor's range check (profiles/README.md)
-                const bool inr = false;
-#else
                 const bool inr = gx < W && c0 < Coutv;
-#endif
                 const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -960,11 +942,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                 // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
                 const int c0 = co_blk + wave * 16 + (kg & 1) * 8;
                 const int rsel = kg >> 1;
-#ifdef UH_ABL_OOBSTORE
-                const bool inr = false;
-#else
                 const bool inr = gx < W && c0 < Coutv;
-#endif
                 const unsigned voff0 = (unsigned)((gx * ldy + c0) * ES + rsel * rbytes);
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
@@ -1070,16 +1048,6 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                     stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = fmaxf(a2 - a1 * a1 * inv_n, 0.f); // M2
                 }
         }
-#ifdef UH_ABL_CLK
-        if (tid == 0) {      // per workgroup: start / end stamps (100 MHz, low 24 bits), core clocks spent
-            float* o = stats + (int64_t)ntile * (2 * Cout + 1) + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;   // the slack behind the counts
-            o[0] = (float)(clk_r0 & 0xFFFFFFull);
-            o[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);
-            o[2] = (float)(__builtin_amdgcn_s_memtime() - clk_t0);
-            // XCC_ID (hwreg 20, low 4 bits) * 65536 + HW_ID (hwreg 4, low 16 bits: wave, simd, pipe, cu, sh, se)
-            o[3] = (float)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 65536u + __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4));
-        }
-#endif
         float* counts = stats + (int64_t)ntile * 2 * Cout;
         if (slab == 0) {
             if (tid == 0) counts[tile_lane] = n_run;
@@ -1505,6 +1473,13 @@ extern "C" int uh_conv3x3_stat_slabs(int B, int H, int W, int Cin, int Cout, int
     return B * ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
 }
 
+// UH_NO_WRES=1 (A/B runs): the 64-input-channel layers take the streaming-filter instantiation instead of the
+// register-resident one.  Read once per process, not per launch.
+static bool uh_no_wres() {
+    static const bool off = getenv("UH_NO_WRES") != nullptr;
+    return off;
+}
+
 template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
@@ -1532,9 +1507,6 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             // persistent workgroups: 2 (NBW=2, VGPR-bound) or 3 (NBW=1) per CU, spread over the channel slabs; the
             // number of tile lanes is rounded to a multiple of 8 for the XCD-aware mapping inside the kernel
             auto lanes_for = [&](int per_cu, int slabs) {
-#ifdef UH_ABL_ONE_PER_CU      // timing-only: one workgroup per CU
-                per_cu = 1;
-#endif
                 int gx = (per_cu * 256 + slabs - 1) / slabs;
                 gx = (gx + 7) & ~7;
                 if (gx > ntile) gx = ntile;
@@ -1554,7 +1526,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                        C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
-            } else if (ES == 2 && !split && !narrow && C0 + C1 == 2 * CK && !getenv("UH_NO_WRES")) {
+            } else if (ES == 2 && !split && !narrow && C0 + C1 == 2 * CK && !uh_no_wres()) {
                 // 64 input channels: the filter stays in registers (2 workgroups per CU: 72 more VGPRs)
                 int slabs = Cout / 64, gx = lanes_for(2, slabs);
                 if constexpr (ES == 2)
@@ -2171,10 +2143,8 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     __builtin_amdgcn_sched_barrier(0);
     int bufi = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
-#ifndef UH_ABL_WG_NODMA
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-#endif
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
         auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
