@@ -10,7 +10,13 @@ fp32 accumulate / statistics / master weights), BCE + Dice + 0.25*boundary loss,
 (RCCL gradient all-reduce when N > 1), clip_grad_norm_(1.0), RMSprop.  N = 1 runs BASELINE config 2
 (UNet(1,1,bilinear=True), batch 8); N > 1 keeps 8 images per GPU (weak scaling) unless --global-batch G is given:
 then every rank takes G / N images (strong scaling; BASELINE config 3 = --global-batch 32 on 8 GPUs).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  For N > 1 the weak-scaling line is the headline and a `strong_gb32` object carries the
+fixed-global-batch-32 measurement (ms/step, images/s, exposed all-reduce time) of the same ranks.
+
+`python bench.py --gpus N` without a torch.distributed environment starts the N ranks ITSELF (fresh child processes, one
+per GPU, rendezvous on 127.0.0.1) before anything in this process has touched the GPU, relays rank 0's JSON line and
+exits with the worst rank's code; under `python -m torch.distributed.run ... bench.py --gpus N` (the driver's form) it is
+one of the ranks and `--gpus` must equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -55,6 +61,9 @@ def parse():
                     help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the global-batch-32 leg (strong_gb32)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only inference timing (clean train-step profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank flow on a one-GPU box together with --share-gpu)")
@@ -145,13 +154,49 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    the contract torch.distributed.run uses) and wait for them.  The parent never initialises the GPU (it only counts
+    devices), so no process that holds a GPU context is ever replaced or forked.  Children inherit stdout / stderr: rank 0
+    prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    share = "--share-gpu" in sys.argv
+    ndev = torch.cuda.device_count()                 # does not create a context
+    if not share and ndev < n:
+        raise SystemExit(f"bench.py --gpus {n}: this machine shows {ndev} GPU(s) (use --share-gpu --backend gloo only to "
+                         "rehearse the multi-rank flow on one GPU)")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:                              # a rank died: do not leave the others waiting at a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))    # decided before torch.cuda is touched
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the train-step path has no CPU fallback")
+        raise SystemExit(f"rank {rank}/{world}: bench.py needs an MI355X: the train-step path has no CPU fallback")
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -181,7 +226,6 @@ def main():
     amp = not args.fp32
     stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=args.side_stream and not args.no_side_stream, cc_loss=args.cc_loss,
                                    fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
-    g = torch.Generator().manual_seed(1 + rank)
     strong = args.global_batch > 0
     if strong:
         if args.global_batch % world:
@@ -189,33 +233,62 @@ def main():
         args.batch = args.global_batch // world
     B, S = args.batch, args.size
     sync = stepper.optimizer.sync
-    if sync is not None:
-        sync.time_exposed = True
-    images = torch.rand(B, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    masks = torch.randint(0, 3, (B, S, S), generator=g).to(dev)
+
+    def make_batch(nb: int, seed: int):
+        g = torch.Generator().manual_seed(seed)
+        im = torch.rand(nb, n_in, S, S, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        mk = torch.randint(0, 3, (nb, S, S), generator=g).to(dev)
+        return im, mk
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    last = None
-    for _ in range(args.warmup):
-        last = stepper.step(images, masks)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = stepper.step(images, masks)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    exposed = sync.exposed_ms()[-args.steps:] if sync is not None else None
-    if sync is not None:
-        sync.time_exposed = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(im, mk, steps: int, warmup: int):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the time is the
+        maximum over the ranks.  -> (seconds, per-step exposed all-reduce ms or None, terms of the last step)"""
+        last = None
+        if sync is not None:
+            sync.time_exposed = False
+        for _ in range(warmup):
+            last = stepper.step(im, mk)
+        if sync is not None:
+            sync.exposed = []
+            sync.time_exposed = True
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = stepper.step(im, mk)
+        barrier()
+        dt = time.perf_counter() - t0
+        exposed = sync.exposed_ms()[-steps:] if sync is not None else None
+        if sync is not None:
+            sync.time_exposed = False
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, exposed, last
+
+    images, masks = make_batch(B, 1 + rank)
+    elapsed, exposed, last = measure(images, masks, args.steps, args.warmup)
     loss = float(last["loss"].detach())
+
+    def exposed_stats(ex):
+        return {"exposed_allreduce_ms_per_step": round(sum(ex) / max(len(ex), 1), 4) if ex else None,
+                "exposed_allreduce_ms_max": round(max(ex), 4) if ex else None}
+
+    # ---- N > 1: the fixed-global-batch leg (BASELINE config 3 = 32 images over the ranks) beside the weak headline
+    strong_gb32 = None
+    if world > 1 and not strong and not args.config4 and 32 % world == 0 and not args.no_strong_leg:
+        b2 = 32 // world
+        im2, mk2 = make_batch(b2, 101 + rank)
+        dt2, ex2, _ = measure(im2, mk2, args.steps, max(2, args.warmup))
+        strong_gb32 = {"global_batch": 32, "per_gpu_batch": b2, "steps": args.steps,
+                       "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                       "images_per_sec": round(32 * args.steps / dt2, 2), "scaling": "strong", **exposed_stats(ex2)}
+        del im2, mk2
 
     # ---- dominant-kernel roofline, measured live with events on the launch stream (one extra step)
     roof = None
@@ -267,6 +340,24 @@ def main():
         except Exception as e:                      # an optional extra must never cost the headline line
             kernels["double_conv_256"] = {"error": repr(e)}
 
+    # ---- sustained leg: a training job is minutes of back-to-back steps, the headline above is a 0.2 s window.  >= 2 s of
+    # continuous steps (every rank takes part: the steps hold collectives), and the 256-channel DoubleConv timed again
+    # right behind them, so that the spread the chip's power state causes is in the record
+    sustained = None
+    if not args.no_sustained:
+        n_sus = max(args.steps, int(args.sustained_seconds / max(elapsed / args.steps, 1e-4)) + 1)
+        dt_s, ex_s, _ = measure(images, masks, n_sus, 0)
+        sustained = {"steps": n_sus, "seconds": round(dt_s, 3), "ms_per_step": round(dt_s / n_sus * 1e3, 3),
+                     "images_per_sec": round(world * B * n_sus / dt_s, 2)}
+        if ex_s:
+            sustained.update(exposed_stats(ex_s))
+        if rank == 0 and kernels is not None:
+            try:
+                kernels["double_conv_256_after_sustained"] = ops.bench_double_conv(
+                    B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
+            except Exception as e:
+                kernels["double_conv_256_after_sustained"] = {"error": repr(e)}
+
     if rank == 0:
         ips = world * B * args.steps / elapsed
         out = {
@@ -286,8 +377,10 @@ def main():
             "train_tflops_per_gpu": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3, 1),
             "conv_roofline_frac_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3 /
                                              (MFMA_BF16_PEAK_TFLOPS if amp else MFMA_F32_PEAK_TFLOPS), 4),
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "sustained": sustained,
         }
+        if strong_gb32 is not None:
+            out["strong_gb32"] = strong_gb32
         if world > 1:
             import torch.distributed as dist
             out["collective"] = {
@@ -295,8 +388,7 @@ def main():
                 "grad_bytes": int(stepper.optimizer.flat_g.numel() * 4), "grad_buckets": len(sync.buckets),
                 # time the launch stream spent waiting for the gradient all-reduce in front of clip + RMSprop (two events
                 # around the waits, nothing else between them): what the overlap with the encoder backward did NOT hide
-                "exposed_allreduce_ms_per_step": round(sum(exposed) / max(len(exposed), 1), 4) if exposed else None,
-                "exposed_allreduce_ms_max": round(max(exposed), 4) if exposed else None,
+                **exposed_stats(exposed),
             }
         if world == 1 and not args.no_inference:
             # forward-only inference (model.eval(): running statistics folded into the conv epilogue)
