@@ -185,6 +185,50 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+def loader_throughput(dev, B: int, S: int, amp: bool):
+    """what it costs to turn DECODED uint8 pixels into the tensors train.py:113-114 hands to the model.
+    host = the reference's per-pixel arithmetic (rotation, /255, label remap: oracle/data_prep_ref.py, numpy, one core) +
+    the fp32 / int64 host-to-device copies; device = uh_batch_prepare fed from pinned uint8 (copy + one kernel)."""
+    import numpy as np
+    from oracle import data_prep_ref as R
+    from unet_amd.utils.data_loading import prepare_batch_device
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(B, S, S, 1), dtype=np.uint8)
+    msk = rng.choice(np.array([0, 128, 255], np.uint8), size=(B, S, S))
+    turns = [b % 4 for b in range(B)]
+    pin_i, pin_m = torch.from_numpy(img).pin_memory(), torch.from_numpy(msk).pin_memory()
+    dt = torch.bfloat16 if amp else torch.float32
+    for _ in range(3):
+        prepare_batch_device(pin_i, pin_m, turns, device=dev, dtype=dt)
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = prepare_batch_device(pin_i, pin_m, turns, device=dev, dtype=dt)
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    di, dm = pin_i.to(dev), pin_m.to(dev)
+    e0.record()
+    for _ in range(n):
+        prepare_batch_device(di, dm, turns, device=dev, dtype=dt)
+    e1.record()
+    torch.cuda.synchronize()
+    t_kernel = e0.elapsed_time(e1) * 1e-3 / n
+    t0 = time.perf_counter()
+    hi, hm = R.prepare_batch([im[..., 0] for im in img], msk, turns)
+    xi = torch.from_numpy(hi).to(dev).contiguous(memory_format=torch.channels_last)
+    xm = torch.from_numpy(hm).to(dev)
+    torch.cuda.synchronize()
+    t_host = time.perf_counter() - t0
+    same = bool(torch.equal(out["image"].float().cpu(), torch.from_numpy(hi).to(dt).float()) and torch.equal(out["mask"].cpu(), torch.from_numpy(hm)))
+    return {"what": f"decoded uint8 {B} x {S}x{S} -> model inputs (x4-rotation by index, /255 rule, label remap); PIL decode excluded on both sides",
+            "device_images_per_sec": round(B / t_dev, 1), "device_ms_per_batch": round(t_dev * 1e3, 3),
+            "device_kernels_only_ms": round(t_kernel * 1e3, 4),
+            "host_numpy_images_per_sec": round(B / t_host, 1), "host_ms_per_batch": round(t_host * 1e3, 2),
+            "host_cores": 1, "bit_equal": same}
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -409,6 +453,11 @@ def main():
             except Exception as e:                  # optional extras never cost the headline line
                 out["inference"] = {"error": repr(e)}
             model.train()
+        if world == 1 and not args.no_cpu_baseline and n_in == 1:
+            try:
+                out["loader"] = loader_throughput(dev, B, S, amp)
+            except Exception as e:
+                out["loader"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(S)

@@ -332,6 +332,22 @@ size_t uh_postprocess_ws_bytes(int B, int H, int W);
 int uh_postprocess_masks(const uint8_t* mask, uint8_t* out, int B, int H, int W, int min_area,
                          int morph_kernel_size, void* ws, size_t ws_bytes, uh_stream stream);
 
+/* ---- input pipeline, device stage  (utils/data_loading.py:65-132, train.py:113-114) ---------------------------
+ * What BasicDataset.__getitem__ does to a DECODED image / mask pair, for a whole batch in one pass:
+ *   img_u8   DEVICE uint8 [B][Hin][Win][C] (C = 1..4, what np.asarray(PIL image) holds), or NULL (masks only)
+ *   mask_u8  DEVICE uint8 [B][Hin][Win] grey levels (255 contour / 128 background / 0 ghost), or NULL (images only)
+ *   turns    DEVICE int [B]: quarter turns counter-clockwise of item b (index % 4 of the x4 augmentation,
+ *            data_loading.py:100-121), or NULL = no rotation.  odd_turns = 1 when the items' turn counts are odd (every
+ *            item of a batch must have the same output shape: Hin x Win for even counts, Win x Hin for odd ones; square
+ *            images may mix them: pass odd_turns = 0)
+ *   image_out  NHWC [B][Ho][Wo][ld_out >= C] in dt (UH_F32 / UH_BF16): u / 255 when the IMAGE holds a value above 1, else
+ *              the raw 0 / 1 value (data_loading.py:86-87); channels C..ld_out-1 are not written
+ *   labels_out int64 [B][Ho][Wo]: 255 -> 2, 128 -> 1, anything else -> 0 (data_loading.py:74-78)
+ *   flags_ws   DEVICE int [B] workspace (per-image "holds a value above 1")
+ * Decode and the BICUBIC / NEAREST rescale of scale < 1 stay on the host. */
+int uh_batch_prepare(const uint8_t* img_u8, int C, const uint8_t* mask_u8, const int* turns, int odd_turns, void* image_out,
+                     int ld_out, int64_t* labels_out, int* flags_ws, int B, int Hin, int Win, int dt, uh_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

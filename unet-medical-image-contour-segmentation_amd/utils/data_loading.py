@@ -8,7 +8,14 @@
 
 Masks are grey images coded 0 = ghost, 128 = background, 255 = contour -> classes 0 / 1 / 2 through a 256-entry lookup
 table; images are rescaled with BICUBIC, masks with NEAREST, and an image is divided by 255 only when it holds a value
-above 1.  Host-side (PIL + numpy): feeding the GPU path is the DataLoader's job.
+above 1.  `ds[i]` is the reference's host path (PIL + numpy).
+
+The device stage (csrc/data_prep.hip, `uh_batch_prepare`): `ds.raw_item(i)` stops after the decode (and, for scale < 1,
+the host-side rotation + rescale) and returns uint8 pixels + the number of quarter turns still to apply;
+`collate_raw` stacks such items into pinned uint8 batches and `prepare_batch_device` turns a batch into the NHWC fp32 /
+bf16 image tensor in [0, 1] and the int64 labels ON THE GPU -- rotation by index, the per-image /255 rule and the label
+remap in one kernel -- so a batch crosses PCIe at 1 + C bytes per pixel instead of 4C + 8 and no PIL / numpy arithmetic
+runs per pixel on the host (above ~1 000 img/s the PIL loader is the bottleneck).
 """
 from __future__ import annotations
 
@@ -102,6 +109,90 @@ class BasicDataset(Dataset):
         classes = self.preprocess(self.mask_values, mask, self.scale, is_mask=True)
         return {"image": torch.from_numpy(np.ascontiguousarray(pixels)).float(),
                 "mask": torch.from_numpy(np.ascontiguousarray(classes)).long()}
+
+
+    def raw_item(self, index: int) -> Dict[str, object]:
+        """Item `index` up to the point where arithmetic starts: uint8 pixels [H, W] or [H, W, C], uint8 mask grey levels
+        [H, W] and `turns`, the quarter turns the device stage still has to apply.  At scale 1 the files are decoded and
+        nothing else (the rescale to the same size is the identity, data_loading.py:66-70); at scale < 1 the host rotates
+        and rescales exactly like `__getitem__` (PIL's resampling is not restated on the device) and turns = 0."""
+        from PIL import Image
+        views = QUARTER_TURNS if self.augment else 1
+        stem, turns = self.ids[index // views], index % views
+        image = load_image(self._only(self.images_dir, stem, "image"))
+        mask = load_image(self._only(self.mask_dir, stem + self.mask_suffix, "mask"))
+        assert image.size == mask.size, f"Image and mask {stem} should be the same size, but are {image.size} and {mask.size}"
+        if self.scale != 1:
+            image = _rescaled(_quarter_turn(image, turns), self.scale, Image.BICUBIC)
+            mask = _rescaled(_quarter_turn(mask, turns), self.scale, Image.NEAREST)
+            turns = 0
+        pixels, grey = np.asarray(image), np.asarray(mask)
+        if pixels.dtype != np.uint8 or grey.dtype != np.uint8:
+            raise TypeError(f"raw_item: {stem} does not decode to 8-bit pixels ({pixels.dtype}, {grey.dtype}); use ds[i]")
+        return {"image_u8": pixels, "mask_u8": grey, "turns": int(turns)}
+
+
+def collate_raw(items, pin: bool = True) -> Dict[str, torch.Tensor]:
+    """Stack `raw_item`s into uint8 batches [B,H,W,C] / [B,H,W] (pinned host memory) + an int32 turn table.  Every item
+    must produce the same output shape: equal decoded sizes and, unless the images are square, turn counts of one parity."""
+    imgs = [it["image_u8"] if it["image_u8"].ndim == 3 else it["image_u8"][..., None] for it in items]
+    shape = imgs[0].shape
+    if any(a.shape != shape for a in imgs) or any(it["mask_u8"].shape != shape[:2] for it in items):
+        raise ValueError("collate_raw: the items of a batch must have one decoded size")
+    turns = [int(it["turns"]) & 3 for it in items]
+    if shape[0] != shape[1] and len({t & 1 for t in turns}) > 1:
+        raise ValueError("collate_raw: non-square images rotated by odd and even quarter turns do not stack")
+    B = len(items)
+    image = torch.empty((B,) + shape, dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+    mask = torch.empty((B,) + shape[:2], dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+    for b, (a, it) in enumerate(zip(imgs, items)):
+        np.copyto(image[b].numpy(), a)
+        np.copyto(mask[b].numpy(), it["mask_u8"])
+    return {"image_u8": image, "mask_u8": mask, "turns": torch.tensor(turns, dtype=torch.int32)}
+
+
+def prepare_batch_device(image_u8: torch.Tensor, mask_u8: torch.Tensor, turns=None, device=None,
+                         dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+    """uint8 batch (host, ideally pinned, or already on the GPU) -> {'image': logical [B,C,H,W] tensor in `dtype`
+    (channels_last memory, values as data_loading.py:86-87 produces them), 'mask': int64 [B,H,W] classes}: what
+    train.py:113-114 hands to the model, with rotation / normalisation / label remap done by ONE kernel on the GPU
+    (`uh_batch_prepare`).  No CPU fallback."""
+    from .. import ops
+    from .._lib import LIB
+    dev = torch.device(device) if device is not None else (image_u8.device if image_u8.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    if dev.type != "cuda":
+        raise RuntimeError("prepare_batch_device needs a GPU (the host path is BasicDataset.__getitem__)")
+    if image_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8:
+        raise TypeError("prepare_batch_device takes uint8 batches (BasicDataset.raw_item / collate_raw)")
+    if image_u8.dim() == 3:
+        image_u8 = image_u8.unsqueeze(-1)
+    B, H, W, C = image_u8.shape
+    if tuple(mask_u8.shape) != (B, H, W) or not 1 <= C <= 4:
+        raise ValueError(f"prepare_batch_device: image batch {tuple(image_u8.shape)} / mask batch {tuple(mask_u8.shape)}")
+    tl = None
+    odd = 0
+    if turns is not None:
+        tl = [int(t) & 3 for t in (turns.tolist() if torch.is_tensor(turns) else turns)]
+        if len(tl) != B:
+            raise ValueError("prepare_batch_device: one turn count per item")
+        par = {t & 1 for t in tl}
+        if H != W and len(par) > 1:
+            raise ValueError("prepare_batch_device: non-square images rotated by odd and even quarter turns do not stack")
+        odd = 1 if (H != W and par == {1}) else 0
+        if not any(tl):
+            tl = None
+    with torch.cuda.device(dev):
+        img_d = image_u8.contiguous().to(dev, non_blocking=True)
+        msk_d = mask_u8.contiguous().to(dev, non_blocking=True)
+        t_d = torch.tensor(tl, dtype=torch.int32).to(dev, non_blocking=True) if tl is not None else None
+        Ho, Wo = (W, H) if odd else (H, W)
+        image = torch.empty((B, Ho, Wo, C), dtype=dtype, device=dev)
+        labels = torch.empty((B, Ho, Wo), dtype=torch.int64, device=dev)
+        flags = torch.empty(B, dtype=torch.int32, device=dev)
+        LIB.call("uh_batch_prepare", img_d.data_ptr(), C, msk_d.data_ptr(), None if t_d is None else t_d.data_ptr(), odd,
+                 image.data_ptr(), C, labels.data_ptr(), flags.data_ptr(), B, H, W, ops._dt(image),
+                 torch.cuda.current_stream().cuda_stream)
+    return {"image": image.permute(0, 3, 1, 2), "mask": labels}
 
 
 class CarvanaDataset(BasicDataset):
