@@ -289,6 +289,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def run_step(im, mk):
+        # equal shards: the global batch is known without asking the other ranks (saves SyncBN's blocking host read per step)
+        return stepper.step(im, mk, global_batch=int(im.shape[0]) * world if args.sync_bn else None)
+
     def measure(im, mk, steps: int, warmup: int):
         """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the time is the
         maximum over the ranks.  -> (seconds, per-step exposed all-reduce ms or None, terms of the last step)"""
@@ -296,14 +300,14 @@ def main():
         if sync is not None:
             sync.time_exposed = False
         for _ in range(warmup):
-            last = stepper.step(im, mk)
+            last = run_step(im, mk)
         if sync is not None:
             sync.exposed = []
             sync.time_exposed = True
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            last = stepper.step(im, mk)
+            last = run_step(im, mk)
         barrier()
         dt = time.perf_counter() - t0
         exposed = sync.exposed_ms()[-steps:] if sync is not None else None
@@ -341,10 +345,10 @@ def main():
         # EVERY rank runs this extra step (it contains the gradient / loss-sum collectives); rank 0 records events
         ops.PROFILE.clear()
         ops.PROFILE_ON = rank == 0
-        side, ops.WGRAD_STREAM = ops.WGRAD_STREAM, None      # time every kernel alone on the launch stream
-        stepper.step(images, masks)
+        side, stepper.wgrad_stream = stepper.wgrad_stream, None      # time every kernel alone on the launch stream
+        run_step(images, masks)
         torch.cuda.synchronize()
-        ops.WGRAD_STREAM = side
+        stepper.wgrad_stream = side
         ops.PROFILE_ON = False
     if rank == 0 and not args.no_kernel_profile:
         agg = {}

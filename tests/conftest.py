@@ -30,3 +30,33 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def randomize_bn_(module, seed):
+    """The BatchNorm randomisation make_golden.py applies before its eval-mode fixtures (same generator, same draw order)."""
+    import torch
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.bias.shape, generator=g) + 0.5)
+
+
+def g14_model_and_batch():
+    """Fixture G14's model (built on the CPU: torch.manual_seed(0) + ctor gives the reference's weights) and batch."""
+    import torch
+    import unet_amd
+    r = load_golden("g14_eval_full_unet_512")
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=True)
+    randomize_bn_(model, 14)
+    with torch.no_grad():
+        model.outc.conv.bias.copy_(torch.from_numpy(r["outc_bias"]))
+    g = torch.Generator().manual_seed(1400)
+    images = torch.rand(2, 1, 512, 512, generator=g)
+    masks = torch.randint(0, 3, (2, 512, 512), generator=g)
+    return r, model, images, masks

@@ -16,7 +16,8 @@ Fixture list: G1 DoubleConv, G2 Down, G3 Up bilinear (+od
 G4 Up convT, G5 OutConv, G6 Dice, G7 boundary_loss, G8 UNet_T 3-step trajectories,
 G9 full UNet scalars, G10 eval-mode logits/masks, G11 depth-5 net from reference parts,
 G12 utils/data_loading.BasicDataset items on synthetic PNG files,
-G13 full-width config-4 / config-5 nets on small images (scalars + first logits).
+G13 full-width config-4 / config-5 nets on small images (scalars + first logits),
+G14 full UNet(1,1,bilinear=True) in eval mode at 2x1x512x512: logits, `logit > 0` masks, margin histogram, Dice.
 """
 import os
 import sys
@@ -382,7 +383,36 @@ def g13_full_width():
     save("g13_full_width", **rec)
 
 
+def g14_eval_full_unet():
+    """evaluate.py:43-66 on the full-width UNet at the benchmarked image size: eval-mode forward (running statistics),
+    `sigmoid(logit) > 0.5` masks, per-image Dice.  Weights = torch.manual_seed(0) + ctor (not stored), BatchNorm affine /
+    running statistics = randomize_bn(m, 14) so that eval mode is not the identity normalisation."""
+    torch.manual_seed(0)
+    m = UNet(1, 1, bilinear=True); randomize_bn(m, 14)
+    m.eval()
+    im, mk = synth_batch(1400, 2, 1, 512, 512)
+    with torch.no_grad():
+        # a freshly initialised head is all-positive: centre the logits on their median (a bias edit, stored below) so that
+        # the `logit > 0` mask is a non-trivial pattern with pixels arbitrarily close to the threshold
+        m.outc.conv.bias -= m(im).median()
+        logits = m(im)
+    a = logits.abs().squeeze(1)
+    scale = float(a.max())
+    edges = np.array([0.0] + [10.0 ** e for e in range(-8, 1)]) * scale          # |logit| / max|logit| decades
+    rec = {"logits": npy(logits), "mask_pred_bits": np.packbits(npy(logits.squeeze(1) > 0).reshape(-1)),
+           "outc_bias": npy(m.outc.conv.bias), "abs_max": np.array(scale), "abs_margin_min": npy(a.min()), "margin_edges": edges,
+           "margin_hist": np.histogram(npy(a).reshape(-1), bins=edges)[0]}
+    t = (mk // 2).float()
+    rec["dice"] = npy(dice_coeff((torch.sigmoid(logits.squeeze(1)) > 0.5).float(), t, reduce_batch_first=False))
+    rec["note"] = np.array("UNet(1,1,True): torch.manual_seed(0) + ctor, randomize_bn(m, 14), eval(); data synth_batch(1400,2,1,512,512)")
+    save("g14_eval_full_unet_512", **rec)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # python make_golden.py g14_eval_full_unet  -> that generator only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_to_g5()
     g6_dice()
     g7_boundary()
@@ -392,3 +422,4 @@ if __name__ == "__main__":
     g9_full_unet()
     g12_data_loading()
     g13_full_width()
+    g14_eval_full_unet()

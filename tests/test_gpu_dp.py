@@ -72,7 +72,7 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert all(r[1] == "ok" for r in res), res
 
 
-def _syncbn_worker(rank, world, port, q):
+def _syncbn_worker(rank, world, port, q, cuts=(0, 2, 4)):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -83,7 +83,7 @@ def _syncbn_worker(rank, world, port, q):
         model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
         stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=False, sync_bn=True)
         im, mk = unet_amd.ellipse_batch(4, 64, seed=21)
-        lo, hi = rank * 2, rank * 2 + 2
+        lo, hi = cuts[rank], cuts[rank + 1]
         out = None
         for _ in range(2):
             out = stepper.step(im[lo:hi].to(dev), mk[lo:hi].to(dev))
@@ -97,10 +97,12 @@ def _syncbn_worker(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-def test_sync_bn_data_parallel_equals_single_process():
-    """TrainStepper(sync_bn=True): two ranks with half the batch each == one process with the whole batch -- parameters,
-    (clipped) gradients, BatchNorm running statistics, BCE and Dice values.  This is the exact global-batch parity
-    option of SURVEY.md 8(e); the default per-rank BatchNorm is what stock DDP does."""
+@pytest.mark.parametrize("cuts", [(0, 2, 4), (0, 3, 4)], ids=["equal-shards", "ragged-3+1"])
+def test_sync_bn_data_parallel_equals_single_process(cuts):
+    """TrainStepper(sync_bn=True): two ranks with half the batch each -- or with 3 and 1 images (the last batch of an
+    epoch) -- == one process with the whole batch: parameters, (clipped) gradients, BatchNorm running statistics, BCE and
+    Dice values.  This is the exact global-batch parity option of SURVEY.md 8(e); the default per-rank BatchNorm is what
+    stock DDP does."""
     import unet_amd
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
@@ -121,7 +123,7 @@ def test_sync_bn_data_parallel_equals_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -149,3 +151,155 @@ def test_sync_bn_data_parallel_equals_single_process():
                 err = float(((run[k] - v).abs() / (1e-4 * v.abs() + 1e-6)).max())
             assert err <= 1.0, f"{k}: {err:.2f} x tolerance"
     assert (res[0][2] == res[1][2]).all()
+
+
+# ------------------------------------------------------------------------------------------ the untested DP pieces
+def _spawn(target, *extra, world=2, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    return sorted(res)
+
+
+def _nan_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import unet_amd
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=False)
+        im, mk = unet_amd.ellipse_batch(4, 64, seed=31)
+        im, mk = im[rank * 2:rank * 2 + 2].to(dev), mk[rank * 2:rank * 2 + 2].to(dev)
+        stepper.step(im, mk)
+        before = stepper.optimizer.flat_p.detach().clone()
+        bad = im.clone()
+        if rank == 1:
+            bad[0, 0, 5, 7] = float("nan")            # ONE rank sees the NaN: every rank must take the same decision
+        raised = False
+        try:
+            stepper.step(bad, mk)
+        except RuntimeError as e:
+            raised = "NaN loss" in str(e)
+        torch.cuda.synchronize()
+        untouched = bool(torch.equal(before, stepper.optimizer.flat_p))
+        t = stepper.step(im, mk)                      # the next step is clean: no stale collective, no stale gradient
+        torch.cuda.synchronize()
+        flat = stepper.optimizer.flat_p.detach().cpu()
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = bool(torch.equal(gathered[0], gathered[1]))
+        finite = bool(torch.isfinite(flat).all()) and bool(torch.isfinite(t["loss"]))
+        moved = not bool(torch.equal(before.cpu(), flat))
+        dist.destroy_process_group()
+        q.put((rank, "ok", raised, untouched, same, finite, moved))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_nan_on_one_rank_aborts_every_rank_and_the_next_step_is_clean():
+    for _, _, raised, untouched, same, finite, moved in _spawn(_nan_worker):
+        assert raised, "a rank did not raise RuntimeError('Fatal: NaN loss detected!')"
+        assert untouched, "the aborted step changed parameters"
+        assert same and finite and moved
+
+
+def _eval_worker(rank, world, port, q, postprocess):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import unet_amd
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+        batches = [dict(zip(("image", "mask"), unet_amd.ellipse_batch(2, 64, seed=40 + i))) for i in range(4)]
+        mine = batches[rank::world]                       # every rank evaluates its shard of the validation set
+        d, dp_, mn = unet_amd.evaluate(model, mine, dev, amp=False, postprocess=postprocess)
+        dist.destroy_process_group()
+        q.put((rank, "ok", float(d), float(dp_), float(mn)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("postprocess", [False, True])
+def test_sharded_evaluate_returns_the_metric_of_the_whole_set(postprocess):
+    import unet_amd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    batches = [dict(zip(("image", "mask"), unet_amd.ellipse_batch(2, 64, seed=40 + i))) for i in range(4)]
+    d, dp_, mn = (float(v) for v in unet_amd.evaluate(model, batches, dev, amp=False, postprocess=postprocess))
+    for _, _, rd, rdp, rmn in _spawn(_eval_worker, postprocess):
+        assert abs(rd - d) < 1e-6 and abs(rdp - dp_) < 1e-6 and abs(rmn - mn) < 1e-6, ((rd, rdp, rmn), (d, dp_, mn))
+
+
+def test_parameter_without_gradient_is_skipped_like_torch_optim():
+    """A parameter that receives no gradient (frozen after construction / unused in this step) must stay exactly where it
+    is -- torch.optim skips parameters whose .grad is None; weight decay / momentum must not move it -- while every other
+    parameter takes the same step as in an unfrozen run whose frozen-parameter gradient is removed from the norm."""
+    import unet_amd
+    dev = torch.device("cuda:0")
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=5)
+    torch.manual_seed(0)
+    model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    opt = unet_amd.FusedRMSprop(model.parameters(), lr=1e-3, weight_decay=1e-2)     # large decay: drift would be visible
+    frozen = [model.up2.conv.double_conv[4].weight, model.up2.conv.double_conv[4].bias, model.down1.maxpool_conv[1].double_conv[0].weight]
+    for step in range(3):
+        for p in frozen:
+            p.requires_grad_(step == 0)          # step 0 builds optimizer state for them, then they are frozen
+        snap = [p.detach().clone() for p in frozen]
+        others = [p.detach().clone() for p in model.parameters() if all(p is not f for f in frozen)]
+        model.train()
+        opt.zero_grad()
+        unet_amd.seg_loss(model(im.to(dev)), mk.to(dev), 1)["loss"].backward()
+        opt.step()
+        torch.cuda.synchronize()
+        if step > 0:
+            for p, s0 in zip(frozen, snap):
+                assert torch.equal(p.detach(), s0), "a parameter without a gradient moved"
+        now = [p.detach() for p in model.parameters() if all(p is not f for f in frozen)]
+        assert any(not torch.equal(a, b) for a, b in zip(now, others))
+    # against stock torch.optim.RMSprop + clip_grad_norm_ on a twin model driven the same way
+    torch.manual_seed(0)
+    twin = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+    topt = torch.optim.RMSprop(twin.parameters(), lr=1e-3, weight_decay=1e-2, momentum=0.999)
+    tfrozen = [twin.up2.conv.double_conv[4].weight, twin.up2.conv.double_conv[4].bias, twin.down1.maxpool_conv[1].double_conv[0].weight]
+    for step in range(3):
+        for p in tfrozen:
+            p.requires_grad_(step == 0)
+        twin.train()
+        topt.zero_grad(set_to_none=True)
+        unet_amd.seg_loss(twin(im.to(dev)), mk.to(dev), 1)["loss"].backward()
+        torch.nn.utils.clip_grad_norm_([p for p in twin.parameters() if p.grad is not None], 1.0)
+        topt.step()
+    for (k, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
+        err = float((a.detach() - b.detach()).abs().max())
+        assert err <= 2e-3, f"{k}: {err:.2e} from stock RMSprop after three steps (one step moves an element by up to 1e-2)"
+
+
+def test_wgrad_stream_choice_is_per_stepper():
+    import unet_amd
+    from unet_amd import ops
+    dev = torch.device("cuda:0")
+    im, mk = unet_amd.ellipse_batch(2, 64, seed=6)
+    a = unet_amd.TrainStepper(unet_amd.UNet_T(1, 1, bilinear=True).to(dev), amp=False, wgrad_stream=True)
+    b = unet_amd.TrainStepper(unet_amd.UNet_T(1, 1, bilinear=True).to(dev), amp=False, wgrad_stream=False)
+    a.step(im.to(dev), mk.to(dev))
+    assert ops.WGRAD_STREAM is a.wgrad_stream and a.wgrad_stream is not None
+    b.step(im.to(dev), mk.to(dev))
+    assert ops.WGRAD_STREAM is None
+    a.step(im.to(dev), mk.to(dev))
+    assert ops.WGRAD_STREAM is a.wgrad_stream           # constructing / stepping b did not take a's side stream away
+    torch.cuda.synchronize()

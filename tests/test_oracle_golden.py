@@ -186,6 +186,22 @@ def test_eval_masks_bit_exact(name, bilinear):
     close(dice, r["dice"], rtol=1e-4)
 
 
+def test_eval_full_unet_512_masks():
+    """Fixture G14: the full-width UNet in eval mode at 2x1x512x512 (evaluate.py:43-66): logits, `logit > 0` masks wherever
+    the reference's own margin is safe, per-image Dice."""
+    from conftest import g14_model_and_batch
+    r, model, images, masks = g14_model_and_batch()
+    st = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    dice, logits = S.evaluate_dice(st, images, masks, n_classes=1, bilinear=True)
+    close(logits, r["logits"], rtol=1e-4, atol=1e-5 * float(r["abs_max"]))
+    want = np.unpackbits(r["mask_pred_bits"])[:2 * 512 * 512].reshape(2, 512, 512).astype(bool)
+    pred = (logits.squeeze(1) > 0).numpy()
+    safe = np.abs(r["logits"]).squeeze(1) > 1e-4 * float(r["abs_max"])
+    assert (pred == want)[safe].all()
+    assert (pred != want).mean() < 1e-3
+    close(dice, r["dice"], rtol=1e-3)
+
+
 def test_init_state_keys_match_reference():
     r = load_golden("g8_unet_t_convt")
     ref_keys = sorted(k[4:] for k in r if k.startswith("sd0."))

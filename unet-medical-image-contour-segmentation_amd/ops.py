@@ -134,10 +134,12 @@ WGRAD_STREAM = None
 GRAD_DST = {}
 
 
-def _grad_buffer(p: torch.Tensor):
+def _grad_buffer(p: torch.Tensor, wanted: bool = True):
     """-> (buffer to write the gradient of `p` into, completion callback or None).  With a callback the gradient is
-    final in the optimizer's flat buffer: the autograd node returns None for it (no AccumulateGrad clone)."""
-    ent = GRAD_DST.get(p.data_ptr())
+    final in the optimizer's flat buffer: the autograd node returns None for it (no AccumulateGrad clone).
+    `wanted=False` (autograd does not need this gradient: a frozen parameter): scratch memory, no callback -- the
+    optimizer must see the parameter as one that received no gradient (torch.optim skips those)."""
+    ent = GRAD_DST.get(p.data_ptr()) if wanted else None
     if ent is not None and ent[0].shape == p.shape and ent[0].stride() == p.stride():
         return ent
     return _empty_like_param(p), None
@@ -589,7 +591,7 @@ class ConvBnReluFn(Function):
             dl = grads[0].float().contiguous()
             ncls = hw2.shape[0]
             head_w, head_b = ctx.head_params
-            (dwb, cb_hw), (dbb, cb_hb) = _grad_buffer(head_w), _grad_buffer(head_b)
+            (dwb, cb_hw), (dbb, cb_hb) = _grad_buffer(head_w, ctx.needs_input_grad[12]), _grad_buffer(head_b, ctx.needs_input_grad[13])
             direct = cb_hw is not None and cb_hb is not None and dwb.stride(0) == Cout and dwb.stride(1) == 1 and \
                 dbb.is_contiguous() and dwb.dtype == torch.float32 and dbb.dtype == torch.float32
             dhw = dwb if direct else torch.empty((ncls, Cout), dtype=torch.float32, device=dev)
@@ -607,7 +609,8 @@ class ConvBnReluFn(Function):
             def apply(part_ptr, nb, dg_ptr, db_ptr, n_total):
                 LIB.call("uh_bn_relu_head_bwd_apply", dl.data_ptr(), hw2.data_ptr(), *bn_args, part_ptr, nb, dg_ptr, db_ptr,
                          dy.data_ptr(), Cout, n, n_total, Cout, ncls, dt, _stream())
-            dhead = (None, None) if direct else (dhw.view(head_w.shape), dhb)
+            dhead = (None, None) if direct else (dhw.view(head_w.shape) if ctx.needs_input_grad[12] else None,
+                                                 dhb if ctx.needs_input_grad[13] else None)
         elif tail == TAIL_POOL and grads[1] is not None:
             dskip, dpool = grads
             dpool = dense_nhwc(dpool if dpool.dtype == y.dtype else dpool.to(y.dtype))
@@ -636,7 +639,7 @@ class ConvBnReluFn(Function):
                          dy.data_ptr(), Cout, n, n_total, Cout, dt, _stream())
         reduce()
         gamma_p, beta_p = ctx.bn_params
-        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
+        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p, ctx.needs_input_grad[3]), _grad_buffer(beta_p, ctx.needs_input_grad[4])
         dy = torch.empty_like(y)
         if ctx.sync_bn is None:
             apply(partials.data_ptr(), nblk, dgamma.data_ptr(), dbeta.data_ptr(), 0)
@@ -690,6 +693,10 @@ class ConvBnReluFn(Function):
             dgamma = None
         if cb_b is not None:
             cb_b()
+            dbeta = None
+        if not ctx.needs_input_grad[3]:
+            dgamma = None
+        if not ctx.needs_input_grad[4]:
             dbeta = None
         return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1]
 
@@ -839,7 +846,7 @@ class ConvBnReluNarrowFn(Function):
         LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(), n, Cout, dt, _stream())
         gamma_p, beta_p = ctx.bn_params
-        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p), _grad_buffer(beta_p)
+        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p, ctx.needs_input_grad[3]), _grad_buffer(beta_p, ctx.needs_input_grad[4])
         dy = torch.empty_like(y)
         if ctx.sync_bn is None:
             LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), y.data_ptr(), Cout, scale.data_ptr(),
@@ -884,6 +891,10 @@ class ConvBnReluNarrowFn(Function):
             dgamma = None
         if cb_b is not None:
             cb_b()
+            dbeta = None
+        if not ctx.needs_input_grad[3]:
+            dgamma = None
+        if not ctx.needs_input_grad[4]:
             dbeta = None
         return dx[0], dx[1], dweight, dgamma, dbeta, None, None, None, None, None, None, None
 
@@ -1080,7 +1091,7 @@ class OutConv1x1Fn(Function):
         # straight into the optimizer's flat gradient buffer when the parameter is registered there (FusedRMSprop) and its
         # [n_classes][Cin] plane is dense -- a 1x1 filter has the same memory order in contiguous and channels_last layout
         weight, bias = ctx.params
-        (dwb, cb_w), (dbb, cb_b) = _grad_buffer(weight), _grad_buffer(bias)
+        (dwb, cb_w), (dbb, cb_b) = _grad_buffer(weight, ctx.needs_input_grad[1]), _grad_buffer(bias, ctx.needs_input_grad[2])
         direct = cb_w is not None and cb_b is not None and dwb.stride(0) == Cin and dwb.stride(1) == 1 and \
             dbb.is_contiguous() and dwb.dtype == torch.float32 and dbb.dtype == torch.float32
         if direct:
@@ -1094,7 +1105,7 @@ class OutConv1x1Fn(Function):
             cb_w()
             cb_b()
             return dx, None, None
-        return dx, dw.view(ctx.wshape), db
+        return dx, dw.view(ctx.wshape) if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None
 
 
 # ----------------------------------------------------------------------------- losses
@@ -1145,7 +1156,7 @@ class SegLossBinaryFn(Function):
             tf = (mk // mask_div).float() if mask_div != 1 else mk.float()
             bl = boundary_loss_value(lg, 1, H * W, tf, B, H, W, edge_width, edge_weight)
         out = torch.empty(4, dtype=torch.float32, device=dev)
-        LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(n * world), _p(bl), float(w_boundary),
+        LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(round(n * world)), _p(bl), float(w_boundary),
                  out.data_ptr(), _stream())
         ctx.save_for_backward(lg, mk, sums)
         ctx.meta = (int(mask_div), n, world, logits.shape, logits.dtype)
@@ -1158,7 +1169,7 @@ class SegLossBinaryFn(Function):
         g0 = gout[0:1].contiguous().float()       # only the total carries gradient
         dl = torch.empty_like(lg)
         LIB.call("uh_bce_dice_grad", lg.data_ptr(), mk.data_ptr(), mask_div, None, n, sums.data_ptr(),
-                 float(n * world), 1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())
+                 float(round(n * world)), 1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())
         dl = dl.view(shape)
         if dtype != torch.float32:
             dl = dl.to(dtype)
@@ -1191,7 +1202,7 @@ class SegLossMulticlassFn(Function):
             # 4-D path of boundary_loss.py:20-23: channel 1 of the logits, target = mask as float
             bl = boundary_loss_value(lg[..., 1], C, H * W * C, mk.float(), B, H, W, edge_width, edge_weight)
         out = torch.empty(4, dtype=torch.float32, device=dev)
-        LIB.call("uh_seg_loss_multiclass_finish", sums.data_ptr(), C, float(npix * world), _p(bl),
+        LIB.call("uh_seg_loss_multiclass_finish", sums.data_ptr(), C, float(round(npix * world)), _p(bl),
                  float(w_boundary), out.data_ptr(), _stream())
         ctx.save_for_backward(lg, mk, sums)
         ctx.meta = (npix, C, world, logits_nhwc.dtype)
@@ -1203,7 +1214,7 @@ class SegLossMulticlassFn(Function):
         npix, C, world, dtype = ctx.meta
         g0 = gout[0:1].contiguous().float()
         dl = torch.empty_like(lg)
-        LIB.call("uh_ce_dice_grad", lg.data_ptr(), mk.data_ptr(), npix, C, sums.data_ptr(), float(npix * world),
+        LIB.call("uh_ce_dice_grad", lg.data_ptr(), mk.data_ptr(), npix, C, sums.data_ptr(), float(round(npix * world)),
                  1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())
         if dtype != torch.float32:
             dl = dl.to(dtype)

@@ -24,7 +24,7 @@ from ._lib import LIB
 
 
 # ----------------------------------------------------------------------------------- loss
-def seg_loss(masks_pred: torch.Tensor, true_masks: torch.Tensor, n_classes: int, *, reduce_sums=None, world: int = 1,
+def seg_loss(masks_pred: torch.Tensor, true_masks: torch.Tensor, n_classes: int, *, reduce_sums=None, world: float = 1,
              boundary_weight: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """train.py:118-142.  masks_pred: logits [B,n_classes,H,W] (as returned by the model);
     true_masks: int64 [B,H,W] with the dataset's values {0,1,2,..} (NOT yet // 2)."""
@@ -178,17 +178,32 @@ class FusedRMSprop:
             raise RuntimeError("FusedRMSprop.step() after close() (another FusedRMSprop took the parameters over)")
         if ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)     # weight gradients written on the side stream
-        # a parameter that received no gradient this step must not re-apply the previous step's (clipped) one: its
-        # slice is zeroed (torch.optim would skip the parameter; with zero gradient only weight decay / momentum act)
+        # A parameter that received no gradient this step is SKIPPED, as torch.optim skips parameters whose .grad is None
+        # (an unused or frozen parameter must not drift under weight decay / momentum): its slice of the flat gradient is
+        # zeroed -- so that it adds nothing to the clipping norm and a data-parallel peer that did produce a gradient still
+        # meets a matching all-reduce -- and the update runs over the contiguous runs of fresh slices only.
         stale = [i for i, f in enumerate(self._fresh) if not f]
-        if stale and len(stale) < len(self._fresh):
+        if stale and len(stale) == len(self._fresh):
+            raise RuntimeError("FusedRMSprop.step() without a backward pass since the last step / zero_grad")
+        runs = [(0, self.total)]
+        if stale:
             for i in stale:
                 o, n = self.slices[i]
                 self.flat_g[o:o + n].zero_()
                 if self.sync is not None:
                     self.sync.mark_ready(i)
-        elif stale:
-            raise RuntimeError("FusedRMSprop.step() without a backward pass since the last step / zero_grad")
+            runs, start = [], None
+            for i, (o, n) in enumerate(self.slices):
+                end = o + (n + 3) // 4 * 4
+                if self._fresh[i]:
+                    if start is None:
+                        start = o
+                    last = end
+                elif start is not None:
+                    runs.append((start, last - start))
+                    start = None
+            if start is not None:
+                runs.append((start, last - start))
         self._fresh = [False] * len(self.params)
         if self.sync is not None:
             self.sync.wait()
@@ -196,9 +211,10 @@ class FusedRMSprop:
         st = torch.cuda.current_stream().cuda_stream
         LIB.call("uh_grad_sumsq", self.flat_g.data_ptr(), self.total, self.norm.data_ptr(), self.ws.data_ptr(),
                  self.ws.numel(), st)
-        LIB.call("uh_rmsprop_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_sq.data_ptr(),
-                 self.flat_buf.data_ptr(), self.total, self.norm.data_ptr(), self.gradient_clipping, float(g["lr"]),
-                 float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]), st)
+        for o, n in runs:
+            LIB.call("uh_rmsprop_step", self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(), self.flat_sq[o:].data_ptr(),
+                     self.flat_buf[o:].data_ptr(), n, self.norm.data_ptr(), self.gradient_clipping, float(g["lr"]),
+                     float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]), st)
         ops.WEIGHT_EPOCH += 1        # parameters changed behind torch's version counters (see ops.packed_w3x3_cached)
         return self.norm
 
@@ -305,10 +321,8 @@ class TrainStepper:
         # overlapping with the BatchNorm / backward-data kernels of the launch stream as intended, and every kernel of
         # the pair then runs about as much slower as the overlap saves (the chip is at its power limit either way) --
         # the step is 2-3 % FASTER on one stream (DESIGN.md "Measured (round 2)").
-        if wgrad_stream and ops.WGRAD_STREAM is None:
-            ops.WGRAD_STREAM = torch.cuda.Stream()
-        elif not wgrad_stream:
-            ops.WGRAD_STREAM = None
+        # (kept on the instance and installed for the duration of step(): another live stepper keeps its own choice)
+        self.wgrad_stream = torch.cuda.Stream() if wgrad_stream else None
         self.amp = amp
         self.check_nan = check_nan
         if fp32_mode not in ("exact", "bf16x3"):
@@ -321,18 +335,33 @@ class TrainStepper:
         # sync_bn: BatchNorm statistics (forward) and their backward sums over the GLOBAL batch -> the data-parallel step
         # reproduces the single-process step on the concatenated batch (SURVEY.md 8e option 2); default = per-rank
         # statistics like stock DDP.  One all_gather (2C+1 floats) + one all_reduce (2C floats) per BatchNorm layer.
-        self.sync_bn = (process_group, self.world) if (sync_bn and self.world > 1) else None
+        # Its collectives run on a process group of their OWN: on the gradient group they would queue, inside RCCL's one
+        # stream per communicator, behind bucket all-reduces that wait for side-stream backward-weights events -- and the
+        # critical-path BatchNorm backward would stall behind work it does not depend on.
+        self.sync_bn = None
+        if sync_bn and self.world > 1:
+            import torch.distributed as dist
+            ranks = dist.get_process_group_ranks(process_group) if process_group is not None else list(range(self.world))
+            self.bn_group = dist.new_group(ranks=ranks)       # collective: every rank of the group constructs its stepper
+            self.sync_bn = (self.bn_group, self.world)
         self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
                                       gradient_clipping=gradient_clipping, process_group=process_group)
         self._pack = None
 
-    def step(self, images, true_masks):
+    def step(self, images, true_masks, global_batch: Optional[int] = None):
+        """One optimizer step (train.py:113-159).  `global_batch` (data parallel with sync_bn): the sum of the ranks' batch
+        sizes when the caller knows it (equal shards: world * B) -- otherwise it is all-reduced here, which costs a blocking
+        host read per step."""
         self.model.train()
+        ops.WGRAD_STREAM = self.wgrad_stream
         ops.SYNC_BN = self.sync_bn
         ops.SYNC_BN_BATCH = None
+        world = self.world
         if self.sync_bn is not None:
             lb = int(images.shape[0])
-            ops.SYNC_BN_BATCH = (dpmod.global_batch(lb, self.group, images.device), lb)
+            gb = int(global_batch) if global_batch is not None else dpmod.global_batch(lb, self.group, images.device)
+            ops.SYNC_BN_BATCH = (gb, lb)
+            world = gb / lb               # ragged shards: the loss is normalised by the GLOBAL pixel count n * gb / lb
         ops.FP32_MODE = self.fp32_mode
         # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
@@ -343,7 +372,7 @@ class TrainStepper:
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
         return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
-                          reduce_sums=self.reduce_sums, world=self.world, check_nan=self.check_nan, cc_loss=self.cc_loss)
+                          reduce_sums=self.reduce_sums, world=world, check_nan=self.check_nan, cc_loss=self.cc_loss)
 
 
 class GraphedTrainStepper(TrainStepper):
@@ -364,6 +393,7 @@ class GraphedTrainStepper(TrainStepper):
 
     def _eager_step(self, images, masks):
         self.model.train()
+        ops.WGRAD_STREAM = self.wgrad_stream
         ops.SYNC_BN = None
         ops.FP32_MODE = self.fp32_mode
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
@@ -447,7 +477,7 @@ def train_model(model, device, train_batches, val_batches=None, epochs: int = 5,
             epoch_loss += terms["loss"].item()                                                # train.py:163
         rec = {"epoch": epoch, "loss": epoch_loss}
         if val_batches is not None:
-            val_score, _, min_score = evaluate(model, val_batches, device, amp, postprocess=False)
+            val_score, _, min_score = evaluate(model, val_batches, device, amp)          # train.py:186 (postprocess=True)
             lr = cosine_warm_restarts_lr(learning_rate, float(val_score))                     # train.py:187
             stepper.optimizer.param_groups[0]["lr"] = lr
             rec.update(val_dice=float(val_score), min_dice=float(min_score), lr=lr)
