@@ -94,6 +94,20 @@ size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt)
 int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
                      const void* x1, int C1, int ld1, float* dw_krsc, int Cout,
                      void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
+/* The BatchNorm + ReLU BETWEEN the two convs of a DoubleConv (unet_parts.py:16-17) applied by the CONSUMER conv's loader
+ * (SURVEY.md section 7 step 6): x0 is the RAW output y_prev of the previous conv and the layer's input
+ *     x = max(y_prev * pre_scale + pre_shift, 0)            (per channel of source 0, rounded to bf16 as uh_bn_relu_apply stores it)
+ * is rebuilt in LDS on its way to the MFMAs -- the activation never exists in HBM, uh_bn_relu_apply is not launched.
+ * Results are bit-identical to the separate-kernel path.  bf16, one source of <= 512 channels (multiple of 64), Cout % 64 == 0,
+ * tensors below 2 GiB: uh_conv3x3_pre_ok() says whether a call qualifies.  dt may carry UH_WFRAG in the forward call.
+ * uh_conv3x3_wgrad_pre: backward-weights of such a layer (workspace: uh_conv3x3_wgrad_ws_bytes); backward-data is the
+ * ordinary uh_conv3x3_fwd on dy with the transposed filter and yields the gradient of x. */
+int uh_conv3x3_pre_ok(int B, int H, int W, int C0, int Cout, int ld0, int ldy, int dt);
+int uh_conv3x3_fwd_pre(const void* x0, int C0, int ld0, const float* pre_scale, const float* pre_shift, const void* w,
+                       void* y, int ldy, int Cout, float* stat_partials, int B, int H, int W, int dt, uh_stream stream);
+int uh_conv3x3_wgrad_pre(const void* dy, int lddy, const void* x0, int C0, int ld0, const float* pre_scale,
+                         const float* pre_shift, float* dw_krsc, int Cout, void* ws, size_t ws_bytes, int B, int H, int W,
+                         int dt, uh_stream stream);
 /* Narrow-tensor forms for the small-width models (UNet_S / UNet_T, unet_model.py:52-126: 8..64-channel layers).  The
  * layer is COMPUTED as the next 64-aligned layer (filters zero-padded to C0 + C1 -> Cout, all multiples of 64, so the MFMA
  * kernels apply), but the tensors in HBM hold only their first C0v / C1v / Coutv channels per pixel (multiples of one

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of one environment switch inside ONE gpurun call (boxes differ by a few percent): bench.py interleaved off/on, twice.
+#   scratch/ab_env.sh UH_FUSE_PRE outdir [extra bench args]
+VAR=$1; OUT=gpurun_out/$2; shift 2
+mkdir -p $OUT
+for i in 1 2; do for f in 0 1; do
+  env $VAR=$f python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-inference --no-sustained "$@" > $OUT/ab_${f}_${i}.json 2> $OUT/ab_${f}_${i}.err
+  python - <<PY
+import json
+j = json.load(open("$OUT/ab_${f}_${i}.json"))
+k = j["kernels"]
+print("$VAR=$f run=$i", j["value"], "img/s", j["ms_per_step"], "ms", {n: (v["calls"], v["ms"]) for n, v in k.items() if "calls" in v}, "dc256", k["double_conv_256"]["all_six"]["tflops"])
+PY
+done; done

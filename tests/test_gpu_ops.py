@@ -142,6 +142,48 @@ def _conv_case(dtype, B, H, W, C0, C1, Cout, tol_f32=2e-5):
     assert rel(dwn, dwref) < tolw, f"wgrad {rel(dwn, dwref):.3e}"
 
 
+@pytest.mark.parametrize("dtype,noise", [(torch.float32, 1e-3), (torch.bfloat16, 0.25)])
+@pytest.mark.parametrize("H,W", [(64, 64), (160, 48), (7, 9)])
+def test_conv3x3_stats_of_near_constant_channels_with_a_corner_outlier(dtype, noise, H, W):
+    """the BatchNorm statistics are pivot-shifted sums; a pivot taken at the image corner would be the one
+    atypical value of a channel that is flat everywhere else (medical backgrounds) and M2 = S2 - S1^2 / n would cancel.
+    Centre-tap filters make every output channel a scaled copy of an input channel = level 5 +- noise, except ONE huge
+    value at pixel (0,0) of image 0; the merged (mean, M2) must match fp64 moments of the stored y."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * 100 + W)
+    B, C = 2, 64
+    x = 5.0 + noise * torch.randn(B, C, H, W, generator=g)
+    x[0, :, 0, 0] = 3000.0
+    w = torch.zeros(C, C, 3, 3)
+    w[torch.arange(C), torch.arange(C), 1, 1] = 1.0 + torch.arange(C) / 64.0
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xg = _nhwc(x, dtype, dev)
+    wf, _ = ops.pack_w3x3(w.to(dev), dtype, False)
+    y, stats, nslab = ops.conv3x3_fwd(xg, None, wf, C, True)
+    st = stats[:nslab * 2 * C].view(nslab, 2, C).double().cpu()
+    cnt = stats[nslab * 2 * C:nslab * 2 * C + nslab].double().cpu()
+    live = cnt > 0
+    st, cnt = st[live], cnt[live]
+    mean = (st[:, 0] * cnt[:, None]).sum(0) / cnt.sum()
+    m2 = (st[:, 1] + cnt[:, None] * (st[:, 0] - mean[None]) ** 2).sum(0)
+    ys = y.double().cpu().reshape(-1, C)
+    # the outlier dominates the true moments; what must survive is the flat part, so compare the moments of everything BUT
+    # the outlier pixel, recovered from the merged ones (exact algebra in double) -- a cancelled S2 - S1^2/n shows up here
+    n = float(cnt.sum())
+    o = ys[0]                                                     # pixel (0,0) of image 0
+    mean_r = (mean * n - o) / (n - 1)
+    m2_r = m2 - (o - mean) ** 2 * n / (n - 1)
+    rest = ys[1:]
+    want_mean, want_m2 = rest.mean(0), ((rest - rest.mean(0)) ** 2).sum(0)
+    assert float(((mean_r - want_mean).abs() / want_mean.abs()).max()) < 1e-5
+    # removing the outlier's (o - mean)^2 ~ 1e7 from M2 in double leaves fp32 round-off of the kernel's own sums: the flat
+    # part's M2 is ~ n * noise^2 * gain^2; allow the kernel's fp32 accumulation (1e-6 of the outlier term) on top of 2 %
+    slack = 2e-2 * want_m2 + 2e-6 * (o - mean) ** 2
+    assert bool(((m2_r - want_m2).abs() <= slack).all()), float(((m2_r - want_m2).abs() / slack).max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3x3_strided_slices(dtype):
     """inputs / outputs that are channel slices of wider buffers (pixel stride > C)."""

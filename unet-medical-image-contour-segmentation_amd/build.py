@@ -94,7 +94,9 @@ def lint_isa(verbose: bool = False) -> None:
             os.remove(os.path.join(OBJ_DIR, src.replace(".hip", ".o")))       # never link a build that failed the lint
             raise RuntimeError("ISA lint failed for " + src + ":\n  " + "\n  ".join(errs))
         if verbose:
-            print(f"isa lint {src}: {len(report)} guarded kernels clean", flush=True)
+            loops = {k: v["scratch_in_enclosing_loops"] for k, v in report.items() if v.get("scratch_in_enclosing_loops")}
+            print(f"isa lint {src}: {len(report)} guarded kernels clean" +
+                  (f"; spill instructions inside MFMA loops (outside the MFMA stream): {sorted(loops.values())}" if loops else ""), flush=True)
 
 
 if __name__ == "__main__":

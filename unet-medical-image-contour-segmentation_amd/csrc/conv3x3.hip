@@ -542,12 +542,21 @@ __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }
 // is loaded ONCE and stays in registers for every tile of the persistent workgroup.  The 64 -> 64 layers at 512 x 512 have
 // only 2 chunks per tile, so every 16x16 tile used to re-read the whole 74 KB filter through L1 (590 MB per launch, more
 // than the activations; TA 82 % busy): with it resident the main loop's only vector-memory traffic is the halo DMA.
-template <typename T, int NBW, bool SPLIT = false, bool WRES = false>
+// PRE (bf16, source 0 only): x0 is the RAW output of the previous conv and the BatchNorm + ReLU that follows it
+// (unet_parts.py:16-17) is applied here, by the consumer: z = max(y * scale + shift, 0) per channel, rounded to bf16 exactly as
+// uh_bn_relu_apply would have stored it -- so the activation between the two convs of a DoubleConv never exists in HBM.  The
+// halo tile still travels HBM -> LDS by DMA; once a wave's own pieces have landed (its covering vmcnt) every thread rewrites
+// the pieces IT issued in place (ds_read_b128 -> 8 x fma / max -> ds_write_b128) in front of the chunk's barrier.  Pieces
+// outside the image stay zero (the padding of the ACTIVATION is zero, not max(shift, 0)).  The 2 * C0 coefficients sit in LDS.
+constexpr int PRE_MAX_C = 512;
+template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false>
 __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
-    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv, int wfrag) {
+    const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv, int wfrag,
+    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
+    static_assert(!PRE || (sizeof(T) == 2 && !SPLIT), "PRE is the bf16 training path");
     // C0 / C1 / Cout are the channel counts the filter pack is laid out for (multiples of a chunk / of 64); C0v / C1v /
     // Coutv (<=) are the channels that exist in memory ("narrow" tensors of the small-width nets): input channels
     // beyond them are fetched as zeros by the DMA, output channels beyond Coutv are computed (zero filters) but not stored.
@@ -564,9 +573,10 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_STRIDE];
     // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
-    // S1 = sum (v - p), S2 = sum (v - p)^2 with p = the channel's first stored value (so that |mean - p| ~ std and the
+    // S1 = sum (v - p), S2 = sum (v - p)^2 with p = one stored value of the channel (so that |mean - p| ~ std and the
     // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
     __shared__ float wg_sum[3][BN];          // [0] = S1, [1] = S2, [2] = pivot; slot = channel - co_blk
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAX_C : 4];     // PRE: (scale, shift) pairs of source 0
     float n_run = 0.f;
 
     const int tid = threadIdx.x;
@@ -739,6 +749,58 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         f = u32x4{hi[0], hi[1], lo[0], lo[1]};
     };
 
+    // PRE: BatchNorm + ReLU of the producer, applied to the pieces THIS thread's DMA has just landed in buffer `bufi_t`
+    // (chunk `c`, the tile the scalars d_* describe).  Called behind the wave's vmcnt(0), in front of the chunk's barrier.
+    auto pre_transform = [&](int c, int bufi_t) {
+        if constexpr (PRE) {
+            const int cc = c * CK;
+            if (cc >= C0) return;                               // second source (skip concatenation): stored activated
+            unsigned char* bufp = lds + bufi_t * HALO2_STRIDE;
+            int tid_o = tid;                                     // (opaque: keeps the slot coordinates out of long-lived registers)
+            asm volatile("" : "+v"(tid_o));
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int p = tid_o + k * 256, q = p >> 2;
+                const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;
+                bool ok = q < HALO_PIX;
+                if (!d_in) ok = ok && (unsigned)(d_y0 - 1 + hy) < (unsigned)H && (unsigned)(d_x0 - 1 + hx) < (unsigned)W;
+                if (ok) {
+                    const int part = (p & 3) ^ halo_swz(hx);
+                    u32x4* slot = reinterpret_cast<u32x4*>(bufp + p * 16);
+                    const u32x4 v = *slot;
+                    const f32x4* t = reinterpret_cast<const f32x4*>(pre_tab + (cc + part * VEC) * 2);
+                    const f32x4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];       // (s0, h0, s1, h1) ...
+                    float r[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r[2 * e] = __uint_as_float(v[e] << 16);
+                        r[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                    }
+                    r[0] = uh_relu(fmaf(r[0], t0[0], t0[1])); r[1] = uh_relu(fmaf(r[1], t0[2], t0[3]));
+                    r[2] = uh_relu(fmaf(r[2], t1[0], t1[1])); r[3] = uh_relu(fmaf(r[3], t1[2], t1[3]));
+                    r[4] = uh_relu(fmaf(r[4], t2[0], t2[1])); r[5] = uh_relu(fmaf(r[5], t2[2], t2[3]));
+                    r[6] = uh_relu(fmaf(r[6], t3[0], t3[1])); r[7] = uh_relu(fmaf(r[7], t3[2], t3[3]));
+                    const bf16x8 o = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3],
+                                      (bf16_t)r[4], (bf16_t)r[5], (bf16_t)r[6], (bf16_t)r[7]};
+                    *slot = __builtin_bit_cast(u32x4, o);
+                }
+            }
+        }
+    };
+    // end of a chunk: the next buffer's DMA (and the asynchronous filter loads) have landed, every wave is done reading the
+    // current buffer.  PRE: the wave's own pieces are rewritten between its vmcnt(0) and the barrier.
+    auto chunk_fence = [&](int c_next, int bufi_next, bool live_next) {
+        if constexpr (PRE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (live_next) pre_transform(c_next, bufi_next);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     // Persistent over tiles.  Every vector-memory operation of the main loop (halo DMA, filter fragments) is issued through
     // inline asm and waited for by hand-counted s_waitcnt: vmcnt retires IN ORDER, so what matters is the ORDER of issue.
     // Per chunk (W* = the NWLOAD fragment loads of one column shift, D = the 6 DMA pieces of the NEXT chunk's halo tile):
@@ -831,8 +893,13 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     } else {
         load_w(wA, chunk_of(0), 0);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRE) {
+        // the coefficient table must be complete before the first rewrite: one extra barrier, once per kernel
+        for (int i = tid; i < C0; i += 256) { pre_tab[2 * i] = pre_scale[i]; pre_tab[2 * i + 1] = pre_shift[i]; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    chunk_fence(chunk_of(0), 0, true);
 
     for (; tile < ntile; tile += nlanes) {
         const int next_tile = tile + nlanes;
@@ -847,18 +914,18 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             for (int v = 0; v < 2; ++v, bufi ^= 1) {
                 const unsigned char* buf = lds + bufi * HALO2_STRIDE;
                 mma_shift(buf, 0, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 0][n]; });
+                bool live_next = true;
                 if (v == 0) {
                     dma_chunk(1, bufi ^ 1, true);
                 } else {
-                    const bool more = next_tile < ntile;
-                    if (more) dma_tile(next_tile);
-                    dma_chunk(0, bufi ^ 1, more);
+                    live_next = next_tile < ntile;
+                    if (live_next) dma_tile(next_tile);
+                    dma_chunk(0, bufi ^ 1, live_next);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mma_shift(buf, 1, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 1][n]; });
                 mma_shift(buf, 2, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 2][n]; });
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                chunk_fence(v == 0 ? 1 : 0, bufi ^ 1, live_next);
             }
         } else {
 #pragma unroll 1
@@ -872,12 +939,13 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             load_w(wC, cur_c, 2);
             // the halo tile of what follows chunk v: the tile's next chunk, else chunk 0 of the workgroup's next tile, else
             // nothing (six out-of-range pieces keep the instruction count of the waits below)
+            bool live_next = true;
             if (v + 1 < nchunk) {
                 dma_chunk(chunk_of(v + 1), bufi ^ 1, true);
             } else {
-                const bool more = next_tile < ntile;
-                if (more) dma_tile(next_tile);
-                dma_chunk(chunk_of(0), bufi ^ 1, more);
+                live_next = next_tile < ntile;
+                if (live_next) dma_tile(next_tile);
+                dma_chunk(chunk_of(0), bufi ^ 1, live_next);
             }
             UH_WAIT_VM(NWLOAD + NLOAD);               // WB landed (WC and the DMA stay in flight)
             mma_shift(buf, 1, wsel(wB));
@@ -885,8 +953,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             UH_WAIT_VM(NLOAD + NWLOAD);               // WC landed (the DMA and WA' stay in flight)
             mma_shift(buf, 2, wsel(wC));
             // DMA and WA' landed; every wave has finished reading this buffer
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            chunk_fence(next_c, bufi ^ 1, live_next);
         }
         }
 
@@ -986,14 +1053,18 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             float* S2 = &wg_sum[1][0];
             float* PV = &wg_sum[2][0];
             if (n_run == 0.f) {
-                // pivot = the tile's first stored value of each channel (pixel (0,0): lane lx == 0 of every lane group)
-                if (lx == 0) {
+                // pivot = one stored value of each channel from the MIDDLE of the workgroup's first tile (pixel (8,8); (0,0) only
+                // when the tile is that small).  The first tile of workgroup 0 is the image corner, where zero padding makes
+                // pixel (0,0) the least typical value of a channel: on a near-constant channel (flat background) a corner pivot
+                // costs eps * (corner - level)^2 of noise per pixel in S2 - S1^2 / n, an interior one costs nothing.
+                const bool mid_r = vy > 8, mid_c = vx > 8;                    // wave-uniform
+                if (lx == (mid_c ? 8 : 0)) {
 #pragma unroll
                     for (int n = 0; n < NBW; ++n)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int cl = ch(kg, n, j);
-                            PV[cl] = acc[0][n][j];
+                            PV[cl] = mid_r ? acc[8][n][j] : acc[0][n][j];
                             S1[cl] = 0.f;
                             S2[cl] = 0.f;
                         }
@@ -1484,8 +1555,10 @@ template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
                                 const float* ep_shift, bool* ep_done, bool split = false, int C0v = -1, int C1v = -1,
-                                int Coutv = -1, bool wfrag = false) {
+                                int Coutv = -1, bool wfrag = false, const float* pre_scale = nullptr,
+                                const float* pre_shift = nullptr) {
     const bool narrow = C0v >= 0;          // narrow tensors: only the LDS-DMA MFMA kernel implements the channel masks
+    const bool pre = pre_scale != nullptr; // BatchNorm + ReLU of the producer applied to source 0 by this kernel's loader
     if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
     // runs the separate scale/shift/ReLU pass
@@ -1517,6 +1590,31 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             if (split && !CAN_SPLIT) { uh_set_error("conv3x3_fwd: bf16x3 needs fp32 tensors"); return UH_EINVAL; }
             if (split && wfrag) { uh_set_error("conv3x3_fwd: bf16x3 filters are KRSC packs"); return UH_EINVAL; }
             if (narrow && wfrag) { uh_set_error("conv3x3_fwd: narrow-tensor calls take KRSC packs"); return UH_EINVAL; }
+            if (pre) {
+                if constexpr (ES == 2) {
+                    if (split || narrow || C0 > PRE_MAX_C) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs a plain bf16 call with at most %d channels in source 0; ask uh_conv3x3_pre_ok first", PRE_MAX_C); return UH_EINVAL; }
+                    const int wf = wfrag ? 1 : 0;
+                    if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
+                        int slabs = Cout / 128, gx = lanes_for(2, slabs);
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, false, false, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wf, pre_scale, pre_shift);
+                    } else if (C0 + C1 == 2 * CK && !uh_no_wres()) {
+                        int slabs = Cout / 64, gx = lanes_for(2, slabs);
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, true, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wf, pre_scale, pre_shift);
+                    } else {
+                        int slabs = Cout / 64, gx = lanes_for(3, slabs);
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, false, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wf, pre_scale, pre_shift);
+                    }
+                    UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2 (BatchNorm+ReLU input)");
+                    *ep_done = ep_scale != nullptr;
+                    return UH_OK;
+                } else {
+                    uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input is a bf16 path; ask uh_conv3x3_pre_ok first");
+                    return UH_EINVAL;
+                }
+            }
             if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
                 if (split) {
@@ -1546,6 +1644,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             *ep_done = ep_scale != nullptr;
             return UH_OK;
         }
+        if (pre) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs the LDS-DMA MFMA kernel (tensors below 2 GiB); ask uh_conv3x3_pre_ok first"); return UH_EINVAL; }
         if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but this call cannot take the LDS-DMA MFMA kernel (a tensor of 2 GiB or more); ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
         if (split) { uh_set_error("conv3x3_fwd: bf16x3 is implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors are implemented for tensors below 2 GiB only"); return UH_EINVAL; }
@@ -1559,6 +1658,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         UH_CHECK_LAUNCH("conv3x3_fwd_mfma");
         return UH_OK;
     }
+    if (pre) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs an MFMA-aligned shape; ask uh_conv3x3_pre_ok first"); return UH_EINVAL; }
     if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but the shape / alignment is outside the MFMA path; ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
     if (split) { uh_set_error("conv3x3_fwd: bf16x3 needs an MFMA-aligned shape (Cin %% 16 == 0, Cout %% 64 == 0, 16-byte strides)"); return UH_EINVAL; }
     if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors need padded counts that are MFMA-aligned and 16-byte strides"); return UH_EINVAL; }
@@ -1636,6 +1736,33 @@ extern "C" int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout
     if (px * ld0 * es >= lim || (C1 && px * ld1 * es >= lim) || px * ldy * es >= lim) return 0;
     if ((int64_t)Cout * 9 * (C0 + C1) * es >= lim) return 0;
     return 1;
+}
+
+// Training forward whose input is the RAW output y_prev of the previous conv: the BatchNorm + ReLU between the two convs of a
+// DoubleConv (unet_parts.py:16-17) is applied by this kernel's loader, x = max(y_prev * pre_scale + pre_shift, 0) rounded to the
+// activation dtype exactly as uh_bn_relu_apply stores it -- the activation itself is never written.  bf16, single source of
+// <= 512 channels, LDS-DMA MFMA kernel only: uh_conv3x3_pre_ok says whether a call qualifies (else run uh_bn_relu_apply).
+extern "C" int uh_conv3x3_pre_ok(int B, int H, int W, int C0, int Cout, int ld0, int ldy, int dt) {
+    if (dt != UH_BF16 || C0 > PRE_MAX_C) return 0;
+    if (C0 % 64 || Cout % 64) return 0;                  // (backward-weights of the same layer works on 64-channel slabs)
+    return uh_conv3x3_wfrag_ok(B, H, W, C0, 0, Cout, ld0, 0, ldy, dt);
+}
+
+extern "C" int uh_conv3x3_fwd_pre(const void* x0, int C0, int ld0, const float* pre_scale, const float* pre_shift, const void* w,
+                                  void* y, int ldy, int Cout, float* stat_partials, int B, int H, int W, int dt,
+                                  uh_stream stream) {
+    UH_REQUIRE(x0 && w && y && pre_scale && pre_shift, "uh_conv3x3_fwd_pre: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && Cout > 0, "uh_conv3x3_fwd_pre: bad shape");
+    UH_REQUIRE(ld0 >= C0 && ldy >= Cout, "uh_conv3x3_fwd_pre: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_fwd_pre: pixel count overflows int32");
+    const bool wfrag = (dt & UH_WFRAG) != 0;
+    dt &= ~UH_WFRAG;
+    UH_REQUIRE(dt == UH_BF16, "uh_conv3x3_fwd_pre: bf16 only (dtype %d)", dt);
+    UH_REQUIRE(uh_conv3x3_pre_ok(B, H, W, C0, Cout, ld0, ldy, dt), "uh_conv3x3_fwd_pre: shape outside the fused path (uh_conv3x3_pre_ok)");
+    bool done;
+    return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, nullptr, 0, 0, (const bf16_t*)w, (bf16_t*)y, ldy, Cout,
+                                        stat_partials, B, H, W, (hipStream_t)stream, nullptr, nullptr, &done, false, -1, -1, -1,
+                                        wfrag, pre_scale, pre_shift);
 }
 
 // Inference forward: z = max(conv(x, w) * scale + shift, 0) with the eval-mode BatchNorm coefficients of
@@ -1981,11 +2108,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // 4 -> 128 co x 64 ci, 8 waves, one workgroup per CU: the x halo image (the operand with the 1.4x halo) is staged once for
 // twice the MFMA work, 30 % fewer DMA bytes / pieces per MFMA -- the kernel is bound by the rate at which L2 / Infinity
 // Cache fill the LDS images (TCC hit rate 26 %, 36 GB/s per CU needed at the full MFMA rate), not by the matrix pipe.
-template <typename T, int NWR>
+// PRE: x0 is the RAW output of the previous conv; its BatchNorm + ReLU (the layer's real input, never stored: see
+// conv3x3_fwd_mfma_v2) is applied to the x image in LDS by the thread that issued the DMA piece, behind the wave's vmcnt(0) and in
+// front of the tile's barrier.  LDS is full (two workgroups x two stages = 160 KiB), so the 64 (scale, shift) pairs of the
+// workgroup's input-channel slab live in ONE register pair spread over the lanes (lane = channel) and reach the lane that needs
+// them through ds_bpermute (the LDS crossbar, no LDS memory).
+template <typename T, int NWR, bool PRE = false>
 __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
-    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv) {
+    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv, const float* __restrict__ pre_scale = nullptr,
+    const float* __restrict__ pre_shift = nullptr) {
     static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
     constexpr int TH = 8;
     constexpr int NT = 128 * NWR;               // threads
@@ -2135,12 +2268,74 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     }
 #endif
 
+    // PRE: lane l of every wave holds (scale, shift) of channel ci0 + l of source 0 (loaded -- and waited for -- before the first
+    // asynchronous DMA is in flight, so that the compiler's own wait for these two loads cannot miscount)
+    float pre_s = 0.f, pre_h = 0.f;
+    const bool pre_on = PRE && ci0 < C0;
+    if constexpr (PRE) {
+        if (pre_on) { pre_s = pre_scale[ci0 + lane]; pre_h = pre_shift[ci0 + lane]; }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_s), "+v"(pre_h) :: "memory");
+    }
+    auto pre_x = [&](int tile, int bufi_t) {
+        if constexpr (PRE) {
+            if (!pre_on) return;
+            int t = tile;
+            const int txt = t % tilesX; t /= tilesX;
+            const int tyt = t % tilesY;
+            const int y0 = tyt * TH, x0p = txt * TILE;
+            const bool inside = y0 >= 1 && y0 + TH + 1 <= H && x0p >= 1 && x0p + TILE + 1 <= W;
+            unsigned char* xs_t = lds + bufi_t * STAGE;
+#pragma unroll
+            for (int k = 0; k < XR; ++k) {
+                bool ok = xg[k] >= 0;
+                const int hy = xg[k] >> 8, hx = xg[k] & 255;
+                if (!inside) ok = ok && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0p - 1 + hx) < (unsigned)W;
+                // every lane takes part in the permutes (they are cross-lane), only valid pieces are rewritten
+                const int p = tid + k * NT;
+                const int u = (p & 7) ^ (((hx >> 1) & 1) << 2);
+                // (two channel quads in turn: 8 coefficients + 4 values live at a time -- the kernel runs at the register limit)
+                u32x4* slot = reinterpret_cast<u32x4*>(xs_t + p * 16);
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) v = *slot;
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    float sc[4], sh[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sc[e] = __int_as_float(__builtin_amdgcn_ds_bpermute((u * 8 + hq * 4 + e) * 4, __float_as_int(pre_s)));
+                        sh[e] = __int_as_float(__builtin_amdgcn_ds_bpermute((u * 8 + hq * 4 + e) * 4, __float_as_int(pre_h)));
+                    }
+                    const float r0 = uh_relu(fmaf(__uint_as_float(v[2 * hq] << 16), sc[0], sh[0]));
+                    const float r1 = uh_relu(fmaf(__uint_as_float(v[2 * hq] & 0xffff0000u), sc[1], sh[1]));
+                    const float r2 = uh_relu(fmaf(__uint_as_float(v[2 * hq + 1] << 16), sc[2], sh[2]));
+                    const float r3 = uh_relu(fmaf(__uint_as_float(v[2 * hq + 1] & 0xffff0000u), sc[3], sh[3]));
+                    const bf16x4 o = {(bf16_t)r0, (bf16_t)r1, (bf16_t)r2, (bf16_t)r3};
+                    const u32x2 ou = __builtin_bit_cast(u32x2, o);
+                    v[2 * hq] = ou[0];
+                    v[2 * hq + 1] = ou[1];
+                }
+                if (ok) *slot = v;
+            }
+        }
+    };
+    // end of a tile: the DMA of the next tile has landed and every wave has finished reading this buffer
+    auto tile_fence = [&](int next_tile, int bufi_next, bool live_next) {
+        if constexpr (PRE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (live_next) pre_x(next_tile, bufi_next);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     // The LDS-DMA is issued through inline asm (uh_dma16): the compiler does not see it, so it does not drain it in front
     // of the tile's first ds_read (which it does for the builtin -- the DMA of tile t+1 then overlapped nothing); it is
     // waited for by hand at the END of tile t, behind its 72 MFMAs per wave.
     if (t_begin < t_end) issue(t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
@@ -2216,9 +2411,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
                         acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
 #endif
-        // the DMA of tile+1 has landed and every wave has finished reading this buffer
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
     }
 
     float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
@@ -2576,10 +2769,12 @@ extern "C" size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
 template <typename T>
 static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, int ld0, const T* x1, int C1, int ld1,
                                   float* dw, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, hipStream_t st,
-                                  bool split = false, int C0v = -1, int C1v = -1, int Coutv = -1) {
+                                  bool split = false, int C0v = -1, int C1v = -1, int Coutv = -1,
+                                  const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
     constexpr int ES = sizeof(T);
     const int Cin = C0 + C1;
     const bool narrow = C0v >= 0;                 // tensors hold fewer channels than the filter is padded to
+    const bool pre = pre_scale != nullptr;        // x0 = raw conv output, BatchNorm + ReLU applied by the loader (bf16 DMA kernel only)
     if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     const bool aligned = uh_aligned16(dy) && uh_aligned16(x0) && (C1 == 0 || uh_aligned16(x1)) && (lddy * ES) % 16 == 0 &&
                          (ld0 * ES) % 16 == 0 && (C1 == 0 || (ld1 * ES) % 16 == 0) && (C0 % 64 == 0);
@@ -2598,6 +2793,10 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     }
     if (split && p.kind != 0) {
         uh_set_error("uh_conv3x3_wgrad: bf16x3 needs an MFMA-aligned shape (channel counts multiples of 64, 16-byte strides)");
+        return UH_EINVAL;
+    }
+    if (pre && !(ES == 2 && p.kind == 0 && dma && !narrow && !split)) {
+        uh_set_error("uh_conv3x3_wgrad_pre: needs the bf16 LDS-DMA kernel (64-aligned channels, tensors below 2 GiB); ask uh_conv3x3_pre_ok first");
         return UH_EINVAL;
     }
     if (p.kind == 2) {
@@ -2619,7 +2818,15 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             if (dma) {
                 // byte extents of the (sliced) source views as seen from their base pointers
                 unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
-                if (p.nwr == 4)
+                if (pre && p.nwr == 4)
+                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
+                                       C0v, C1v, Coutv, pre_scale, pre_shift);
+                else if (pre)
+                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 2, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
+                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
+                                       C0v, C1v, Coutv, pre_scale, pre_shift);
+                else if (p.nwr == 4)
                     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
                                        lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
                                        C0v, C1v, Coutv);
@@ -2688,6 +2895,22 @@ extern "C" int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0
                                               ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st);
     return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
                                          dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3);
+}
+
+// Backward-weights of a layer whose forward was uh_conv3x3_fwd_pre: x0 is the RAW output of the previous conv and the layer's
+// real input max(x0 * pre_scale + pre_shift, 0) is rebuilt by the loader (it was never stored).  Same result, bit for bit, as
+// uh_conv3x3_wgrad on the stored activation.  Workspace: uh_conv3x3_wgrad_ws_bytes.
+extern "C" int uh_conv3x3_wgrad_pre(const void* dy, int lddy, const void* x0, int C0, int ld0, const float* pre_scale,
+                                    const float* pre_shift, float* dw_krsc, int Cout, void* ws, size_t ws_bytes, int B, int H,
+                                    int W, int dt, uh_stream stream) {
+    UH_REQUIRE(dy && x0 && dw_krsc && pre_scale && pre_shift, "uh_conv3x3_wgrad_pre: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && Cout > 0, "uh_conv3x3_wgrad_pre: bad shape");
+    UH_REQUIRE(lddy >= Cout && ld0 >= C0, "uh_conv3x3_wgrad_pre: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_wgrad_pre: pixel count overflows int32");
+    UH_REQUIRE(dt == UH_BF16, "uh_conv3x3_wgrad_pre: bf16 only (dtype %d)", dt);
+    UH_REQUIRE(C0 % 64 == 0 && Cout % 64 == 0, "uh_conv3x3_wgrad_pre: channel counts must be multiples of 64");
+    return conv3x3_wgrad_dispatch<bf16_t>((const bf16_t*)dy, lddy, (const bf16_t*)x0, C0, ld0, nullptr, 0, 0, dw_krsc, Cout, ws,
+                                          ws_bytes, B, H, W, (hipStream_t)stream, false, -1, -1, -1, pre_scale, pre_shift);
 }
 
 // Narrow variant (see uh_conv3x3_fwd_narrow): the filter gradient is that of the PADDED layer [Cout][3][3][C0 + C1]; x0 / x1 /

@@ -6,6 +6,7 @@ logical NCHW views.  Everything here requires GPU tensors: there is no CPU fallb
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -344,6 +345,20 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
                  0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
 
 
+def conv3x3_wgrad_pre(dy: torch.Tensor, x0_raw: torch.Tensor, pre_coef: torch.Tensor, out_krsc: torch.Tensor):
+    """Backward-weights of a layer whose input is max(x0_raw * scale + shift, 0) (BatchNorm + ReLU of the producer, applied by
+    the loader; pre_coef = [scale | shift | ...] of C0 entries each)."""
+    B, H, W, Cout = dy.shape
+    C0 = x0_raw.shape[3]
+    dt = _dt(dy)
+    nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, C0, Cout, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    with _Timed("conv3x3_wgrad_mfma", 2.0 * B * H * W * Cout * 9 * C0):
+        LIB.call("uh_conv3x3_wgrad_pre", dy.data_ptr(), pixel_ld(dy), x0_raw.data_ptr(), C0, pixel_ld(x0_raw),
+                 pre_coef.data_ptr(), pre_coef[C0:].data_ptr(), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt,
+                 _stream())
+
+
 def bench_double_conv(B: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.dtype, iters: int = 20):
     """Time the conv kernels of one DoubleConv(Cin -> Cout -> Cout) in isolation: preallocated buffers, the C ABI
     called back to back (`iters` launches between two HIP events on the launch stream, so the figure is kernel
@@ -461,6 +476,26 @@ def head_tail_ok(x0: torch.Tensor, Cout: int, head_weight: torch.Tensor) -> bool
                 LIB.query("uh_bn_relu_head_ok", Cout, head_weight.shape[0], _dt(x0)))
 
 
+# BatchNorm + ReLU BETWEEN the two convs of a DoubleConv applied by the second conv's loaders (uh_conv3x3_fwd_pre /
+# uh_conv3x3_wgrad_pre): the first layer's node is asked to `defer` its activation (it returns its raw conv output + the
+# BatchNorm coefficients), the second takes them as `pre_coef`; the activation is never stored.  bf16 training, 64-aligned
+# layers of <= 512 mid channels; bit-identical to the stored-activation path (tests/test_gpu_pre_fusion.py).
+# OFF by default -- measured (round 3, one MI355X, config 2, A/B inside one gpurun call): the nine uh_bn_relu_apply launches it
+# removes cost 0.37 ms / step and 2.0 GB of traffic; rebuilding the activation in LDS costs the nine forward convs +0.15 ms and
+# the nine backward-weights convs +1.0 ms (two workgroups own all of LDS there, so the coefficients travel by ds_bpermute,
+# and the rewrite runs once per 8x16 tile whose halo is 1.4x its pixels): 798 -> 735 images/s.  UH_FUSE_PRE=1 turns it on.
+FUSE_PRE = os.environ.get("UH_FUSE_PRE", "0") == "1"
+
+
+def pre_fuse_ok(x0: torch.Tensor, mid: int, Cout: int) -> bool:
+    """May the (BatchNorm -> ReLU) between a DoubleConv's convs be applied by the second conv's loader?  x0: the block's
+    NHWC input (gives batch, extent, dtype); mid / Cout: channels of the activation in question and of the second conv."""
+    if not FUSE_PRE or x0.dtype != torch.bfloat16:
+        return False
+    B, H, W, _ = x0.shape
+    return bool(LIB.query("uh_conv3x3_pre_ok", B, H, W, mid, Cout, mid, Cout, UH_BF16))
+
+
 class ConvBnReluFn(Function):
     """(nn.Conv2d(3x3, pad 1, no bias) -> nn.BatchNorm2d -> nn.ReLU) of unet_parts.py:15-17 / 18-20 as
     one autograd node.  Inputs: x0 (+ optional x1 = second half of the channel concat of
@@ -472,7 +507,12 @@ class ConvBnReluFn(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
-                training: bool, momentum: float, eps: float, tail: int = 0, head_w=None, head_b=None):
+                training: bool, momentum: float, eps: float, tail: int = 0, head_w=None, head_b=None,
+                defer: bool = False, pre_coef=None):
+        """`defer` (training, no tail): the BatchNorm + ReLU of THIS layer is left to its consumer -- returns (y, coef): the raw
+        conv output standing in for the activation (its gradient is the activation's gradient) and the [scale | shift | mean
+        | rstd] coefficients.  `pre_coef`: x0 is such a raw output; its BatchNorm + ReLU is applied by this layer's conv
+        loaders (forward and backward-weights), the activation is never stored."""
         _require_gpu(x0, "activation")
         x0 = dense_nhwc(x0)
         x1 = None if x1 is None else dense_nhwc(x1)
@@ -481,6 +521,10 @@ class ConvBnReluFn(Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         if Cin != C0 + C1:
             raise RuntimeError(f"conv expects {Cin} input channels, got {C0}+{C1}")
+        if pre_coef is not None and (x1 is not None or not training or pre_coef.numel() != 4 * C0):
+            raise RuntimeError("ConvBnReluFn: a deferred BatchNorm+ReLU input needs a single-source training-mode layer")
+        if defer and (not training or tail != TAIL_NONE):
+            raise RuntimeError("ConvBnReluFn: defer is a training-mode option of layers without a fused tail")
         need_dx = any(ctx.needs_input_grad[:2])
         cdt = conv_dt(x0, C0, C1, Cout, need_dx and training)
         # fragment-major filter packs where the LDS-DMA MFMA kernel runs (forward: this call; backward-data: the conv of dy
@@ -505,7 +549,16 @@ class ConvBnReluFn(Function):
         if training:
             global BN_STATS_EPOCH
             BN_STATS_EPOCH += 1                   # running statistics are about to change under torch's feet
-            y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt, frag_f)
+            if pre_coef is None:
+                y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt, frag_f)
+            else:
+                y = torch.empty((B, H, W, Cout), dtype=x0.dtype, device=dev)
+                nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, C0, Cout, cdt)
+                stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=dev)
+                with _Timed("conv3x3_fwd_mfma", 2.0 * B * H * W * Cout * 9 * C0):
+                    LIB.call("uh_conv3x3_fwd_pre", x0.data_ptr(), C0, pixel_ld(x0), pre_coef.data_ptr(), pre_coef[C0:].data_ptr(),
+                             wf.data_ptr(), y.data_ptr(), Cout, Cout, stats.data_ptr(), B, H, W,
+                             cdt | (UH_WFRAG if frag_f else 0), _stream())
             nbt = num_batches_tracked
             fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
             nbt_ptr = nbt.data_ptr() if fused_nbt else None
@@ -541,6 +594,13 @@ class ConvBnReluFn(Function):
         ctx.n_total = n_total
         ctx.sync_bn = SYNC_BN if n_total != n else None
         ctx.tail = tail
+        ctx.pre = pre_coef is not None
+        if pre_coef is not None:
+            x1 = pre_coef                      # rides in the saved-tensor slot of the (absent) second source
+        if defer:
+            ctx.save_for_backward(x0, x1, y, coef, wd, weight)
+            ctx.mark_non_differentiable(coef)
+            return y, coef
         if tail == TAIL_HEAD:
             ncls = head_w.shape[0]
             hw2 = head_w.reshape(ncls, Cout).contiguous().float()
@@ -575,6 +635,9 @@ class ConvBnReluFn(Function):
         B, H, W, C0, C1, Cout = ctx.dims
         if not ctx.training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the train path")
+        pre_coef = None
+        if ctx.pre:
+            pre_coef, x1 = x1, None
         Cin = C0 + C1
         n = B * H * W
         dev = y.device
@@ -627,7 +690,7 @@ class ConvBnReluFn(Function):
         else:
             dz = grads[0]
             if dz is None:          # pool tail whose outputs were both unused
-                return (None,) * 14
+                return (None,) * 16
             dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
 
             def reduce():
@@ -664,6 +727,13 @@ class ConvBnReluFn(Function):
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
         dweight = None
         side_done = None
+
+        def run_wgrad(out_):
+            if pre_coef is None:
+                conv3x3_wgrad(dy, x0, x1, out_, ctx.cdt == UH_F32X3)
+            else:
+                conv3x3_wgrad_pre(dy, x0, pre_coef, out_)
+
         if ctx.needs_input_grad[2]:
             dweight, cb_w = _grad_buffer(weight)
             if cb_w is not None and WGRAD_STREAM is not None and _is_krsc_dense(weight):
@@ -672,17 +742,17 @@ class ConvBnReluFn(Function):
                 ev.record()                         # dy (and this layer's backward-data) are enqueued before this point
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    conv3x3_wgrad(dy, x0, x1, dweight, ctx.cdt == UH_F32X3)
+                    run_wgrad(dweight)
                     side_done = torch.cuda.Event()
                     side_done.record()              # the gradient all-reduce of this parameter's bucket waits for THIS
-                for t_ in (dy, x0, x1):
+                for t_ in (dy, x0, x1, pre_coef):
                     if t_ is not None:
                         t_.record_stream(side)      # the caching allocator must not recycle them under the side stream
             elif _is_krsc_dense(weight):
-                conv3x3_wgrad(dy, x0, x1, dweight, ctx.cdt == UH_F32X3)
+                run_wgrad(dweight)
             else:
                 dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
-                conv3x3_wgrad(dy, x0, x1, dwk, ctx.cdt == UH_F32X3)
+                run_wgrad(dwk)
                 sO, sI, sH, sW = dweight.stride()
                 LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
             if cb_w is not None:
@@ -698,7 +768,7 @@ class ConvBnReluFn(Function):
             dgamma = None
         if not ctx.needs_input_grad[4]:
             dbeta = None
-        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1]
+        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None
 
 
 # ----------------------------------------------------------------------------- small-width conv + BN + ReLU

@@ -46,7 +46,7 @@ def _finish_tail(z, tail):
 
 
 def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, keep_padded: bool = False,
-                  x0_channels: int = None, tail=None):
+                  x0_channels: int = None, tail=None, defer: bool = False, pre_coef=None):
     """One (conv3x3 -> BatchNorm -> ReLU) layer, plus its consumer `tail` (see _finish_tail) -- fused into the BatchNorm
     kernels where csrc/bn_fused.hip covers the shape (training, 64-aligned layers), separate kernels otherwise.
     Layers whose channel counts are not multiples of 64 (the small-width UNet_S / UNet_T of unet_model.py:52-126) are computed as the next larger 64-aligned layer with zero filters / unit
@@ -69,11 +69,15 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
     if Cp0 == C0 and Cp1 == C1 and Cop == Cout and x0_channels is None:
         args = (x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training, momentum,
                 bn.eps)
+        if defer:      # (the caller has checked ops.pre_fuse_ok: this layer's BatchNorm + ReLU is applied by its consumer)
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, True, None)
         if training and tail == "pool" and ops.pool_tail_ok(x0, Cout):
-            return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None)
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None, False, pre_coef)
         if training and isinstance(tail, OutConv) and ops.head_tail_ok(x0, Cout, tail.conv.weight):
-            return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias)
-        return _finish_tail(ops.ConvBnReluFn.apply(*args), tail)
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias, False, pre_coef)
+        return _finish_tail(ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, False, pre_coef), tail)
+    if defer or pre_coef is not None:
+        raise RuntimeError("a deferred BatchNorm+ReLU needs 64-aligned layers (ops.pre_fuse_ok)")
     if ops.NARROW_IO and x0_channels is None:
         # tensors keep their real channel count in HBM, only the arithmetic is padded (ops.ConvBnReluNarrowFn); the
         # 1- / 3-channel image is widened to one 16-byte piece so that it can be fetched like any other activation
@@ -125,6 +129,14 @@ class DoubleConv(nn.Module):
         unet_parts.py:32 of the next Down) or the network's OutConv (returns its logits)."""
         seq = self.double_conv
         mid = seq[0].weight.shape[0]
+        w1, w2 = seq[0].weight, seq[3].weight
+        cin1 = w1.shape[1]
+        aligned1 = (cin1 <= 4 and x1 is None and mid == 64) or (x0.shape[-1] % CPAD == 0 and (x1 is None or x1.shape[-1] % CPAD == 0))
+        if self.training and aligned1 and mid % CPAD == 0 and w2.shape[0] % CPAD == 0 and ops.pre_fuse_ok(x0, mid, w2.shape[0]):
+            # the activation between the two convs never exists: the second conv's loaders apply the first layer's
+            # BatchNorm + ReLU to its raw output on the way to the MFMAs (SURVEY.md section 7 step 6)
+            y1, coef1 = _conv_bn_relu(x0, x1, seq[0], seq[1], True, defer=True)
+            return _conv_bn_relu(y1, None, seq[3], seq[4], True, tail=tail, pre_coef=coef1)
         h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training, keep_padded=True)
         return _conv_bn_relu(h, None, seq[3], seq[4], self.training, x0_channels=mid if h.shape[-1] != mid else None,
                              tail=tail)
