@@ -31,7 +31,7 @@ def rows_of(d):
 
 def main():
     dfetch, dwrite, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")
+    out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.json")
     rf, rw = rows_of(dfetch), rows_of(dwrite)
 
     def agg(rows, counter):
@@ -70,10 +70,14 @@ def main():
     out = {
         "_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 2 --warmup 1 "
                 "--no-cpu-baseline --no-kernel-profile --no-inference; counter values / 1e3 = MB per launch, averaged per kernel family",
-        "_calibration": "WRITE_SIZE is exact. FETCH_SIZE: fully coalesced 16 B/lane streaming kernels (rmsprop: 4 x 69 MB arrays, "
-                        "bn_relu_apply) read exactly 2x the raw value (MI355X_MICROARCH.md) -> fetch_x2 for them. The conv kernels' halo DMA "
-                        "fetches 64-byte segments (4 lanes x 16 B per pixel chunk): the per-layer table (conv_layers) shows raw FETCH_SIZE "
-                        "against the input bytes of every launch -> fetch_raw for conv3x3_*_mfma.",
+        "_calibration": "WRITE_SIZE is exact (16 B/lane stores). FETCH_SIZE: fully coalesced 16 B/lane streaming kernels (rmsprop: 4 x 69 MB "
+                        "arrays, bn_relu_apply) read exactly 2x the raw value (MI355X_MICROARCH.md) -> fetch_x2 for them. For the conv kernels "
+                        "(halo DMA in 64-byte segments: 4 lanes x 16 B per pixel chunk) the raw value is a LOWER BOUND, not a byte count: the "
+                        "per-layer table (conv_layers) has raw FETCH_SIZE / input bytes of 0.6-0.95 on the large layers (every input byte must "
+                        "be read at least once, so part of these requests is tallied below its size) and 2.8-4.5 on the deep ones (the filter "
+                        "is re-fetched past the 4 MiB L2).  fetch_raw is what the family totals use for conv3x3_*_mfma, so hbm_MB / "
+                        "step_total_GB are lower bounds too; what they do show is the absence of gross re-reads (nothing near 2x the "
+                        "algorithmic bytes on the layers that dominate the traffic).",
         "source_sha256": sha, "families": fams, "conv_layers": table,
     }
     for fam in ("conv3x3_fwd_mfma", "conv3x3_wgrad_mfma"):

@@ -303,3 +303,53 @@ def test_wgrad_stream_choice_is_per_stepper():
     a.step(im.to(dev), mk.to(dev))
     assert ops.WGRAD_STREAM is a.wgrad_stream           # constructing / stepping b did not take a's side stream away
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ the real backend, one rank
+def _rccl_one_rank_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["UH_DP_FORCE_SYNC"] = "1"          # run the collectives although the group has one rank
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import unet_amd
+        torch.manual_seed(0)
+        model = unet_amd.UNet_S(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=True, wgrad_stream=True)
+        sync = stepper.optimizer.sync
+        assert sync is not None and sync.active and dist.get_backend() == "nccl"
+        sync.time_exposed = True
+        im, mk = unet_amd.ellipse_batch(4, 96, seed=3)
+        for _ in range(3):
+            t = stepper.step(im.to(dev), mk.to(dev))
+        torch.cuda.synchronize()
+        ex = sync.exposed_ms()
+        q.put((rank, "ok", stepper.optimizer.flat_p.cpu().numpy(), float(t["loss"]), len(sync.buckets), len(ex)))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_bucketed_gradient_sync_runs_over_rccl_with_one_rank():
+    """RCCL refuses two ranks on one device, so on a one-GPU box the N > 1 tests above travel over gloo.  This one runs the
+    SAME code against the real backend with a one-rank group (UH_DP_FORCE_SYNC=1): loss-sum all-reduces, per-bucket asynchronous
+    all-reduces issued from the side stream's events, handle waits in front of the fused optimizer -- every collective is the
+    identity, so three steps must leave the parameters bit-identical to a plain single-process run."""
+    import unet_amd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unet_amd.UNet_S(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+    st = unet_amd.TrainStepper(model, lr=1e-4, amp=True, wgrad_stream=True)
+    im, mk = unet_amd.ellipse_batch(4, 96, seed=3)
+    for _ in range(3):
+        t = st.step(im.to(dev), mk.to(dev))
+    torch.cuda.synchronize()
+    ref_p, ref_loss = st.optimizer.flat_p.cpu(), float(t["loss"])
+    st.optimizer.close()
+    (_, _, p, loss, nbuckets, nex), = _spawn(_rccl_one_rank_worker, world=1)
+    assert nbuckets >= 1 and nex == 3
+    assert loss == ref_loss and torch.equal(torch.from_numpy(p), ref_p)

@@ -14,6 +14,7 @@ Works on any backend (tests use gloo on CPU tensors for the bucket logic).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -24,9 +25,18 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def sync_enabled(group=None) -> bool:
+    """Do the data-parallel collectives run?  With more than one rank, always.  UH_DP_FORCE_SYNC=1 also runs them in a ONE-rank
+    process group: every collective is then the identity, but it goes through the real backend -- the way to execute the
+    bucket / stream / handle logic against RCCL on a one-GPU box (tests/test_gpu_dp.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("UH_DP_FORCE_SYNC") == "1"
+
+
 def make_sum_reducer(group=None):
     """Callable that all-reduces (sum) a small tensor in place; None when not distributed."""
-    if world_size(group) == 1:
+    if not sync_enabled(group):
         return None
 
     def _reduce(t: torch.Tensor):
@@ -54,6 +64,7 @@ class BucketedGradSync:
         self.flat = flat_grad
         self.group = group
         self.world = world_size(group)
+        self.active = sync_enabled(group)
         self.slices = list(slices)                  # (offset, numel) per parameter, in flat order
         limit = max(1, bucket_bytes // flat_grad.element_size())
         self.buckets: List[Tuple[int, int]] = []    # (start, end) element ranges
@@ -84,7 +95,7 @@ class BucketedGradSync:
         self.handles = []
 
     def _launch(self, b: int):
-        if self.launched[b] or self.world == 1:
+        if self.launched[b] or not self.active:
             self.launched[b] = True
             return
         s, e = self.buckets[b]
@@ -123,7 +134,7 @@ class BucketedGradSync:
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
-        timed = self.time_exposed and self.flat.is_cuda and self.world > 1
+        timed = self.time_exposed and self.flat.is_cuda and self.active
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()

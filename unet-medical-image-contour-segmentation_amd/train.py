@@ -105,7 +105,7 @@ class FusedRMSprop:
                 # alive for as long as the parameter lives) and its handle is kept so that close() can remove it
                 self._hooks.append(p.register_post_accumulate_grad_hook(_weak_grad_hook(self)))
         self.sync = None
-        if dpmod.world_size(process_group) > 1:
+        if dpmod.sync_enabled(process_group):
             self.sync = dpmod.BucketedGradSync(self.flat_g, slices, bucket_bytes, process_group)
 
     def close(self):
