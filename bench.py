@@ -387,6 +387,13 @@ def main():
             kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
         except Exception as e:                      # an optional extra must never cost the headline line
             kernels["double_conv_256"] = {"error": repr(e)}
+        # the same six kernels at the extent the layer has in BASELINE config 3's global batch (32 images): eight tiles per
+        # resident workgroup instead of two, the 75 MB of backward-weights slabs amortised over 4x the pixels
+        if amp and B == 8 and S == 512 and not args.config4:
+            try:
+                kernels["double_conv_256_batch32"] = ops.bench_double_conv(32, S // 4, S // 4, 128, 256, torch.bfloat16, iters=10)
+            except Exception as e:
+                kernels["double_conv_256_batch32"] = {"error": repr(e)}
 
     # ---- sustained leg: a training job is minutes of back-to-back steps, the headline above is a 0.2 s window.  >= 2 s of
     # continuous steps (every rank takes part: the steps hold collectives), and the 256-channel DoubleConv timed again
