@@ -83,6 +83,29 @@ int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout, int ld0, 
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
                    int B, int H, int W, int dt, uh_stream stream);
+/* The stem of the network with a RECOMPUTED output (inc.double_conv.0-2: Conv2d(1 -> 64) -> BatchNorm2d -> ReLU on a single-channel image,
+ * unet_parts.py:15-17; unet_model.py:15): the conv output y costs 9 * Cin multiply-adds per element and is the largest tensor of
+ * the model, so it is never stored -- every consumer rebuilds it from the image with the stored path's FMA order and roundings.
+ *   uh_stem_stats               per-workgroup BatchNorm statistics rows of y (layout / row count of uh_conv3x3_fwd: feed uh_bn_finalize)
+ *   uh_stem_bn_relu_fwd         z = max(round_bf16(conv(x, w)) * scale + shift, 0)
+ *   uh_stem_bn_relu_bwd_reduce  partials[uh_stem_nblk()][2][64] = {sum dz [z>0], sum dz [z>0] xhat}  (finish with uh_bn_bwd_finalize)
+ *   uh_stem_bn_relu_bwd_wgrad   dw[64][3][3][Cin] = sum dy (x) x with dy = scale * (dz [z>0] - dbeta/n - xhat * dgamma/n) rounded
+ *                               to bf16 as uh_bn_relu_bwd_apply would store it (n_total: pixel count of the statistics, 0 = B*H*W)
+ * bf16, Cin = 1, w = KRSC pack [64][9][Cin] (uh_pack_w3x3); dz / z 16-byte aligned.  uh_stem_ok() says whether a layer qualifies. */
+int uh_stem_ok(int Cin, int Cout, int dt);
+int uh_stem_nblk(int B, int H, int W);
+int uh_stem_stats(const void* x, int Cin, int ldx, const void* w, float* stat_partials, int B, int H, int W, int dt,
+                  uh_stream stream);
+int uh_stem_bn_relu_fwd(const void* x, int Cin, int ldx, const void* w, const float* scale, const float* shift, void* z, int ldz,
+                        int B, int H, int W, int dt, uh_stream stream);
+int uh_stem_bn_relu_bwd_reduce(const void* dz, int lddz, const void* x, int Cin, int ldx, const void* w, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, float* partials, int B, int H, int W,
+                               int dt, uh_stream stream);
+size_t uh_stem_bwd_wgrad_ws_bytes(int B, int H, int W, int Cin);
+int uh_stem_bn_relu_bwd_wgrad(const void* dz, int lddz, const void* x, int Cin, int ldx, const void* w, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, const float* dgamma, const float* dbeta,
+                              int64_t n_total, float* dw_krsc, void* ws, size_t ws_bytes, int B, int H, int W, int dt,
+                              uh_stream stream);
 /* Inference form of (Conv2d -> BatchNorm2d(eval) -> ReLU)  (unet_parts.py:15-20 under model.eval(),
  * evaluate.py:30 / predict.py:17): z = max(conv(x, w)*scale + shift, 0) with scale/shift from
  * uh_bn_eval_coeffs, applied to the accumulators -- the pre-BatchNorm tensor is never written. */

@@ -541,14 +541,8 @@ class ConvBnReluFn(Function):
         ctx.cdt = cdt
         ctx.frag_d = frag_d
         dev = x0.device
-        coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
-        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
         n = B * H * W
-        g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
-        b32 = beta if beta.dtype == torch.float32 else beta.float()
         if training:
-            global BN_STATS_EPOCH
-            BN_STATS_EPOCH += 1                   # running statistics are about to change under torch's feet
             if pre_coef is None:
                 y, stats, nslab = conv3x3_fwd(x0, x1, wf, Cout, True, cdt, frag_f)
             else:
@@ -559,23 +553,9 @@ class ConvBnReluFn(Function):
                     LIB.call("uh_conv3x3_fwd_pre", x0.data_ptr(), C0, pixel_ld(x0), pre_coef.data_ptr(), pre_coef[C0:].data_ptr(),
                              wf.data_ptr(), y.data_ptr(), Cout, Cout, stats.data_ptr(), B, H, W,
                              cdt | (UH_WFRAG if frag_f else 0), _stream())
-            nbt = num_batches_tracked
-            fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
-            nbt_ptr = nbt.data_ptr() if fused_nbt else None
-            n_total = n
-            if SYNC_BN is None:
-                LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(),
-                         _p(running_mean), _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(),
-                         shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, _stream())
-            else:
-                # local (mean, M2) first -- running statistics untouched -- then the cross-rank merge
-                m2 = torch.empty(Cout, dtype=torch.float32, device=dev)
-                LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(), None, None,
-                         None, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                         rstd.data_ptr(), m2.data_ptr(), _stream())
-                n_total = _sync_bn_forward(coef, m2, n, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps)
-            if nbt is not None and not fused_nbt:
-                nbt.add_(1)
+            coef, n_total = _bn_train_coefficients(stats, nslab, Cout, n, gamma, beta, running_mean, running_var,
+                                                   num_batches_tracked, momentum, eps)
+            scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
         else:
             # inference (model.eval(): evaluate.py:30, predict.py:17): running statistics -> per-channel scale/shift,
             # applied with the ReLU inside the conv epilogue; nothing is kept for a backward pass
@@ -769,6 +749,132 @@ class ConvBnReluFn(Function):
         if not ctx.needs_input_grad[4]:
             dbeta = None
         return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None
+
+
+# ----------------------------------------------------------------------------- the stem, output recomputed
+# The first layer of the network (inc.double_conv.0-2: Conv2d(Cin <= 4 -> 64) -> BatchNorm2d -> ReLU) with its conv output
+# RECOMPUTED by every consumer instead of stored (csrc/conv3x3.hip, stem_bn_bwd_v3): 9 multiply-adds per element against four HBM
+# passes over the largest tensor of the model.  bf16 training, single-channel images by default (STEM_RECOMPUTE_MAX_CIN).
+STEM_RECOMPUTE = os.environ.get("UH_STEM_RECOMPUTE", "1") != "0"
+STEM_RECOMPUTE_MAX_CIN = 1
+
+
+def stem_recompute_ok(x0: torch.Tensor, Cin: int, Cout: int) -> bool:
+    return bool(STEM_RECOMPUTE and x0.dtype == torch.bfloat16 and Cin <= STEM_RECOMPUTE_MAX_CIN and x0.shape[-1] == Cin and
+                LIB.query("uh_stem_ok", Cin, Cout, UH_BF16) and x0.shape[0] * x0.shape[1] * x0.shape[2] < 2 ** 31)
+
+
+def _bn_train_coefficients(stats, nslab, Cout, n, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
+    """Per-channel [scale | shift | mean | rstd] from the conv kernels' statistics rows (+ running statistics /
+    num_batches_tracked update, + the cross-rank merge under SyncBN).  -> (coef, n_total)"""
+    global BN_STATS_EPOCH
+    BN_STATS_EPOCH += 1
+    dev = stats.device
+    coef = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+    scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
+    g32 = gamma if gamma.dtype == torch.float32 else gamma.float()
+    b32 = beta if beta.dtype == torch.float32 else beta.float()
+    nbt = num_batches_tracked
+    fused_nbt = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
+    nbt_ptr = nbt.data_ptr() if fused_nbt else None
+    n_total = n
+    if SYNC_BN is None:
+        LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(), _p(running_mean),
+                 _p(running_var), nbt_ptr, float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                 rstd.data_ptr(), None, _stream())
+    else:
+        m2 = torch.empty(Cout, dtype=torch.float32, device=dev)
+        LIB.call("uh_bn_finalize", stats.data_ptr(), nslab, Cout, n, g32.data_ptr(), b32.data_ptr(), None, None, None,
+                 float(momentum), float(eps), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                 m2.data_ptr(), _stream())
+        n_total = _sync_bn_forward(coef, m2, n, Cout, g32, b32, running_mean, running_var, nbt_ptr, momentum, eps)
+    if nbt is not None and not fused_nbt:
+        nbt.add_(1)
+    return coef, n_total
+
+
+class StemConvBnReluFn(Function):
+    """(Conv2d(1 -> 64, 3x3, pad 1, no bias) -> BatchNorm2d -> ReLU) of unet_parts.py:15-17 for the network's first
+    layer in training: the conv output is never written; statistics, the activation, the BatchNorm-backward sums and the
+    filter gradient are each computed from the IMAGE (uh_stem_*).  The image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x0, weight, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float):
+        _require_gpu(x0, "image")
+        x0 = dense_nhwc(x0)
+        B, H, W, Cin = x0.shape
+        Cout = weight.shape[0]
+        if weight.shape[1] != Cin or not stem_recompute_ok(x0, Cin, Cout):
+            raise RuntimeError("StemConvBnReluFn: bf16 single-channel image into 64 output channels only")
+        dev = x0.device
+        hit = WEIGHT_PACK.lookup(weight, x0.dtype, False, False) if WEIGHT_PACK is not None else None
+        wf = hit[0] if hit is not None else pack_w3x3(weight, x0.dtype, False)[0]
+        n = B * H * W
+        nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, Cin, Cout, UH_BF16)
+        stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=dev)
+        with _Timed("conv3x3_fwd_stem", 2.0 * n * Cout * 9 * Cin):
+            LIB.call("uh_stem_stats", x0.data_ptr(), Cin, pixel_ld(x0), wf.data_ptr(), stats.data_ptr(), B, H, W, UH_BF16, _stream())
+        coef, n_total = _bn_train_coefficients(stats, nslab, Cout, n, gamma, beta, running_mean, running_var,
+                                               num_batches_tracked, momentum, eps)
+        z = torch.empty((B, H, W, Cout), dtype=x0.dtype, device=dev)
+        with _Timed("conv3x3_fwd_stem", 2.0 * n * Cout * 9 * Cin):
+            LIB.call("uh_stem_bn_relu_fwd", x0.data_ptr(), Cin, pixel_ld(x0), wf.data_ptr(), coef.data_ptr(), coef[Cout:].data_ptr(),
+                     z.data_ptr(), Cout, B, H, W, UH_BF16, _stream())
+        ctx.save_for_backward(x0, coef, wf, weight)
+        ctx.bn_params = (gamma, beta)
+        ctx.dims = (B, H, W, Cin, Cout)
+        ctx.n_total = n_total
+        ctx.sync_bn = SYNC_BN if n_total != n else None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, coef, wf, weight = ctx.saved_tensors
+        B, H, W, Cin, Cout = ctx.dims
+        dev = x0.device
+        dz = dense_nhwc(dz if dz.dtype == x0.dtype else dz.to(x0.dtype))
+        scale, shift, mean, rstd = coef[:Cout], coef[Cout:2 * Cout], coef[2 * Cout:3 * Cout], coef[3 * Cout:]
+        args = (dz.data_ptr(), pixel_ld(dz), x0.data_ptr(), Cin, pixel_ld(x0), wf.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr())
+        nblk = LIB.query("uh_stem_nblk", B, H, W)
+        partials = torch.empty(nblk * 2 * Cout, dtype=torch.float32, device=dev)
+        LIB.call("uh_stem_bn_relu_bwd_reduce", *args, partials.data_ptr(), B, H, W, UH_BF16, _stream())
+        gamma_p, beta_p = ctx.bn_params
+        (dgamma, cb_g), (dbeta, cb_b) = _grad_buffer(gamma_p, ctx.needs_input_grad[2]), _grad_buffer(beta_p, ctx.needs_input_grad[3])
+        LIB.call("uh_bn_bwd_finalize", partials.data_ptr(), nblk, Cout, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+        sums_g, sums_b = dgamma, dbeta
+        if ctx.sync_bn is not None:             # the dy formula needs the GLOBAL sums; the parameter gradients stay local
+            import torch.distributed as dist
+            glob = torch.cat([dgamma.reshape(-1), dbeta.reshape(-1)])
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.sync_bn[0])
+            sums_g, sums_b = glob[:Cout], glob[Cout:]
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            dweight, cb_w = _grad_buffer(weight)
+            nbytes = LIB.query("uh_stem_bwd_wgrad_ws_bytes", B, H, W, Cin)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            direct = _is_krsc_dense(weight)
+            dwk = dweight if direct else torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
+            with _Timed("conv3x3_wgrad_stem", 2.0 * B * H * W * Cout * 9 * Cin):
+                LIB.call("uh_stem_bn_relu_bwd_wgrad", *args, sums_g.data_ptr(), sums_b.data_ptr(), ctx.n_total, dwk.data_ptr(),
+                         ws.data_ptr(), nbytes, B, H, W, UH_BF16, _stream())
+            if not direct:
+                sO, sI, sH, sW = dweight.stride()
+                LIB.call("uh_unpack_dw3x3", dwk.data_ptr(), dweight.data_ptr(), sO, sI, sH, sW, Cout, Cin, _stream())
+            if cb_w is not None:
+                cb_w(None)
+                dweight = None
+        if cb_g is not None:
+            cb_g()
+            dgamma = None
+        if cb_b is not None:
+            cb_b()
+            dbeta = None
+        if not ctx.needs_input_grad[2]:
+            dgamma = None
+        if not ctx.needs_input_grad[3]:
+            dbeta = None
+        return None, dweight, dgamma, dbeta, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- small-width conv + BN + ReLU

@@ -67,6 +67,10 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
     Cp1 = _rup(C1) if C1 else 0
     Cop = _rup(Cout)
     if Cp0 == C0 and Cp1 == C1 and Cop == Cout and x0_channels is None:
+        if stem and training and tail is None and not defer and pre_coef is None and ops.stem_recompute_ok(x0, Cin, Cout):
+            # the network's first layer: its conv output is recomputed by every consumer instead of stored
+            return ops.StemConvBnReluFn.apply(x0, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                              momentum, bn.eps)
         args = (x0, x1, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training, momentum,
                 bn.eps)
         if defer:      # (the caller has checked ops.pre_fuse_ok: this layer's BatchNorm + ReLU is applied by its consumer)
