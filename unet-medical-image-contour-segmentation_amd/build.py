@@ -14,7 +14,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libunet_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 
-SOURCES = ["uh_error.hip", "conv3x3.hip", "bn.hip", "bn_fused.hip", "pool_up.hip", "convt_1x1.hip", "convt_mfma.hip", "loss.hip", "optim.hip", "cc_loss.hip", "infer.hip", "post_process.hip", "data_prep.hip"]
+SOURCES = ["uh_error.hip", "conv3x3.hip", "bn.hip", "bn_fused.hip", "pool_up.hip", "convt_1x1.hip", "convt_mfma.hip", "loss.hip", "optim.hip", "cc_loss.hip", "infer.hip", "post_process.hip", "data_prep.hip", "stem_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # sources whose kernels carry hand-counted waits around inline-asm loads: their device ISA is kept (-save-temps) and

@@ -3144,6 +3144,11 @@ static int stem_fwd_launch(const bf16_t* x, int Cin, int ldx, const bf16_t* w, b
     return 0;
 }
 
+static bool uh_stem_valu() {
+    static const bool on = getenv("UH_STEM_VALU") != nullptr;     // A/B: the serial-FMA recompute kernels instead of the MFMA ones
+    return on;
+}
+
 #define UH_STEM_COMMON(fn)                                                                                                    \
     UH_REQUIRE(x && w, fn ": null pointer");                                                                                  \
     UH_REQUIRE(B > 0 && H > 0 && W > 0 && ldx >= Cin, fn ": bad shape");                                                      \
@@ -3154,6 +3159,9 @@ extern "C" int uh_stem_stats(const void* x, int Cin, int ldx, const void* w, flo
                              uh_stream stream) {
     UH_STEM_COMMON("uh_stem_stats");
     UH_REQUIRE(stat_partials, "uh_stem_stats: null statistics buffer");
+    if (!uh_stem_valu())
+        return uh_stem_mfma_launch(0, x, ldx, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0,
+                                   stat_partials, B, H, W, uh_stem_nblk(B, H, W), stream);
     stem_fwd_launch((const bf16_t*)x, Cin, ldx, (const bf16_t*)w, nullptr, 64, stat_partials, nullptr, nullptr, B, H, W, (hipStream_t)stream);
     UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3 (statistics only)");
     return UH_OK;
@@ -3164,6 +3172,9 @@ extern "C" int uh_stem_bn_relu_fwd(const void* x, int Cin, int ldx, const void* 
     UH_STEM_COMMON("uh_stem_bn_relu_fwd");
     UH_REQUIRE(scale && shift && z && ldz >= 64, "uh_stem_bn_relu_fwd: null pointer / bad stride");
     UH_REQUIRE(uh_aligned16(z) && (ldz * 2) % 16 == 0, "uh_stem_bn_relu_fwd: z must be 16-byte aligned with a 16-byte pixel pitch");
+    if (!uh_stem_valu())
+        return uh_stem_mfma_launch(1, x, ldx, w, scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, z, ldz, nullptr,
+                                   B, H, W, uh_stem_nblk(B, H, W), stream);
     stem_fwd_launch((const bf16_t*)x, Cin, ldx, (const bf16_t*)w, (bf16_t*)z, ldz, nullptr, scale, shift, B, H, W, (hipStream_t)stream);
     UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3 (BatchNorm + ReLU of the rounded output)");
     return UH_OK;
@@ -3175,6 +3186,9 @@ extern "C" int uh_stem_bn_relu_bwd_reduce(const void* dz, int lddz, const void* 
     UH_STEM_COMMON("uh_stem_bn_relu_bwd_reduce");
     UH_REQUIRE(dz && scale && shift && mean && rstd && partials && lddz >= 64, "uh_stem_bn_relu_bwd_reduce: null pointer / bad stride");
     UH_REQUIRE(uh_aligned16(dz) && (lddz * 2) % 16 == 0, "uh_stem_bn_relu_bwd_reduce: dz must be 16-byte aligned with a 16-byte pixel pitch");
+    if (!uh_stem_valu())
+        return uh_stem_mfma_launch(2, x, ldx, w, scale, shift, mean, rstd, nullptr, nullptr, 0.f, dz, lddz, nullptr, 0, partials, B, H,
+                                   W, uh_stem_nblk(B, H, W), stream);
     stem_bwd_launch<0>((const bf16_t*)dz, lddz, (const bf16_t*)x, Cin, ldx, (const bf16_t*)w, scale, shift, mean, rstd, nullptr,
                        nullptr, 0.f, partials, B, H, W, (hipStream_t)stream);
     UH_CHECK_LAUNCH("stem_bn_bwd_v3 (sums)");
@@ -3197,9 +3211,15 @@ extern "C" int uh_stem_bn_relu_bwd_wgrad(const void* dz, int lddz, const void* x
     hipStream_t st = (hipStream_t)stream;
     const float inv_n = (float)(1.0 / (double)(n_total > 0 ? n_total : (int64_t)B * H * W));
     float* slabs = (float*)ws;
-    stem_bwd_launch<1>((const bf16_t*)dz, lddz, (const bf16_t*)x, Cin, ldx, (const bf16_t*)w, scale, shift, mean, rstd, dgamma, dbeta,
-                       inv_n, slabs, B, H, W, st);
-    UH_CHECK_LAUNCH("stem_bn_bwd_v3 (filter gradient)");
+    if (!uh_stem_valu()) {
+        int rc = uh_stem_mfma_launch(3, x, ldx, w, scale, shift, mean, rstd, dgamma, dbeta, inv_n, dz, lddz, nullptr, 0, slabs, B, H, W,
+                                     uh_stem_nblk(B, H, W), stream);
+        if (rc != UH_OK) return rc;
+    } else {
+        stem_bwd_launch<1>((const bf16_t*)dz, lddz, (const bf16_t*)x, Cin, ldx, (const bf16_t*)w, scale, shift, mean, rstd, dgamma, dbeta,
+                           inv_n, slabs, B, H, W, st);
+        UH_CHECK_LAUNCH("stem_bn_bwd_v3 (filter gradient)");
+    }
     const int64_t n = (int64_t)64 * 9 * Cin;
     const int nsplit = uh_stem_nblk(B, H, W);
     if (n % 4 != 0 || !uh_aligned16(dw_krsc) || !uh_aligned16(slabs))

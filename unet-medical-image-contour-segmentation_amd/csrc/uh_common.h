@@ -36,6 +36,12 @@ void uh_set_error(const char* fmt, ...);
 
 static inline bool uh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// stem_mfma.hip (internal): the recomputed stem on the matrix pipe; mode 0 statistics, 1 activation, 2 BatchNorm-backward sums,
+// 3 filter-gradient slabs.  Called by the uh_stem_* entry points of conv3x3.hip.
+int uh_stem_mfma_launch(int mode, const void* x, int ldx, const void* w, const float* scale, const float* shift, const float* mean,
+                        const float* rstd, const float* dgamma, const float* dbeta, float inv_n, const void* dz, int lddz, void* z,
+                        int ldz, float* out, int B, int H, int W, int grid, uh_stream stream);
+
 // ------------------------------------------------------------------ dtype helpers (device)
 template <typename T> struct uh_traits;
 template <> struct uh_traits<float> {
