@@ -83,15 +83,19 @@ int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout, int ld0, 
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
                    int B, int H, int W, int dt, uh_stream stream);
-/* The stem of the network with a RECOMPUTED output (inc.double_conv.0-2: Conv2d(1 -> 64) -> BatchNorm2d -> ReLU on a single-channel image,
- * unet_parts.py:15-17; unet_model.py:15): the conv output y costs 9 * Cin multiply-adds per element and is the largest tensor of
- * the model, so it is never stored -- every consumer rebuilds it from the image with the stored path's FMA order and roundings.
+/* The stem of the network with a RECOMPUTED output (inc.double_conv.0-2: Conv2d(1 -> 64) -> BatchNorm2d -> ReLU on a
+ * single-channel image, unet_parts.py:15-17; unet_model.py:15): the conv output y costs 9 multiply-adds per element and is the
+ * largest tensor of the model, so it is never stored -- every consumer rebuilds it from the image on the matrix pipe (a GEMM
+ * with K = 9: csrc/stem_mfma.hip) with the roundings of the stored path (y to bf16 before BatchNorm, dy to bf16 before the
+ * contraction).  The MFMA adds the nine products in its own order: against the serial-FMA stem kernel of uh_conv3x3_fwd, y
+ * differs by one bf16 ulp on about one element in 10^4; all four entry points use the same arithmetic, so the backward pass
+ * sees exactly the forward pass's ReLU mask and xhat.
  *   uh_stem_stats               per-workgroup BatchNorm statistics rows of y (layout / row count of uh_conv3x3_fwd: feed uh_bn_finalize)
  *   uh_stem_bn_relu_fwd         z = max(round_bf16(conv(x, w)) * scale + shift, 0)
  *   uh_stem_bn_relu_bwd_reduce  partials[uh_stem_nblk()][2][64] = {sum dz [z>0], sum dz [z>0] xhat}  (finish with uh_bn_bwd_finalize)
- *   uh_stem_bn_relu_bwd_wgrad   dw[64][3][3][Cin] = sum dy (x) x with dy = scale * (dz [z>0] - dbeta/n - xhat * dgamma/n) rounded
+ *   uh_stem_bn_relu_bwd_wgrad   dw[64][3][3][1] = sum dy (x) x with dy = scale * (dz [z>0] - dbeta/n - xhat * dgamma/n) rounded
  *                               to bf16 as uh_bn_relu_bwd_apply would store it (n_total: pixel count of the statistics, 0 = B*H*W)
- * bf16, Cin = 1, w = KRSC pack [64][9][Cin] (uh_pack_w3x3); dz / z 16-byte aligned.  uh_stem_ok() says whether a layer qualifies. */
+ * bf16, Cin = 1, w = KRSC pack [64][9][1] (uh_pack_w3x3); dz / z 16-byte aligned.  uh_stem_ok() says whether a layer qualifies. */
 int uh_stem_ok(int Cin, int Cout, int dt);
 int uh_stem_nblk(int B, int H, int W);
 int uh_stem_stats(const void* x, int Cin, int ldx, const void* w, float* stat_partials, int B, int H, int W, int dt,

@@ -2,8 +2,7 @@
 recomputation on the matrix pipe: csrc/stem_mfma.hip).  Same roundings as the stored-output path (y rounded to bf16 before
 BatchNorm, dy before the contraction); the MFMA adds the nine products of a conv output in its own order, so y may differ in
 the last fp32 bit = one bf16 ulp on about one element in 10^4, and the sums are formed in another order: everything agrees
-with the stored path to bf16 / fp32 round-off, nothing more is claimed.  (UH_STEM_VALU=1 selects serial-FMA recompute kernels
-whose forward IS bit-identical to the stored path.)"""
+with the stored path to bf16 / fp32 round-off, nothing more is claimed."""
 import pytest
 import torch
 

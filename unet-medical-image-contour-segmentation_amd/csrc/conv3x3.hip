@@ -1346,9 +1346,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
                                                            T* __restrict__ y, int ldy, float* __restrict__ stats, int B,
                                                            int H, int W, int tilesX, int tilesY,
                                                            const float* __restrict__ ep_scale,
-                                                           const float* __restrict__ ep_shift, int ep_round_first = 0) {
-    // y == nullptr: statistics only (the stem's output is recomputed by its consumers, uh_stem_*); ep_round_first: the
-    // scale / shift / ReLU epilogue acts on the conv output ROUNDED to T -- the training-mode BatchNorm + ReLU of a stored y
+                                                           const float* __restrict__ ep_shift) {
     constexpr int V = 8, COUT = 64;
     __shared__ float xs[HALO_PIX * CIN];
     __shared__ float kshift[COUT];
@@ -1422,16 +1420,12 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_stem_v3(const T* __restrict__
                         for (int i = 0; i < V; ++i) a[i] = fmaf(xv, wr[(r * 3 + ss) * CIN + ci][i], a[i]);
                     }
             if (ep_scale) {
-                if (ep_round_first) {
-#pragma unroll
-                    for (int i = 0; i < V; ++i) a[i] = uh_round_as<T>(a[i]);
-                }
 #pragma unroll
                 for (int i = 0; i < V; ++i) a[i] = uh_relu(fmaf(a[i], esc[i], esh[i]));
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) out[j][i] = uh_round_as<T>(a[i]);
-            if (y && ty < vy && tx < vx) uh_store<T, V>(y + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + g * V, out[j]);
+            if (ty < vy && tx < vx) uh_store<T, V>(y + (int64_t)((b * H + y0 + ty) * W + x0p + tx) * ldy + g * V, out[j]);
         }
         if (stats) {
             if (!have_k) {
@@ -2458,195 +2452,6 @@ __global__ void slab_reduce_scalar_kernel(const float* __restrict__ slabs, float
     out[i] = s;
 }
 
-// =====================================================================================
-// Stem with a RECOMPUTED output (Cin <= 4 -> 64, bf16): the first conv of the network reads a 1-channel image and writes a
-// 64-channel 512 x 512 tensor -- the largest activation of the model for 9 multiply-adds per element.  Its consumers therefore
-// recompute it from the image instead of reading it back: the conv output y never exists in HBM.
-//   forward   conv3x3_fwd_stem_v3(y = NULL)                     statistics only
-//             conv3x3_fwd_stem_v3(ep_round_first)                z = max(round(conv) * scale + shift, 0)
-//   backward  stem_bn_bwd_reduce_v3                              sums of BatchNorm + ReLU backward from dz and the image
-//             stem_bn_bwd_wgrad_v3                               dy = scale * (dz [z>0] - sum1/n - xhat * sum2/n) formed in
-//                                                                registers and contracted with the image: the filter gradient
-// Every value is rebuilt with the FMA order and the roundings of the stored path (y rounded to T before BatchNorm, dy rounded
-// to T before the contraction), so the results match it to the last bit wherever the summation order is the same.
-// =====================================================================================
-template <typename T, int CIN>
-__device__ __forceinline__ void stem_conv8(const float* __restrict__ xs, int ty, int tx, const float (&wr)[9 * CIN][8], float (&a)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int ss = 0; ss < 3; ++ss)
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                const float xv = xs[((ty + r) * HALO_W + tx + ss) * CIN + ci];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = fmaf(xv, wr[(r * 3 + ss) * CIN + ci][i], a[i]);
-            }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = uh_round_as<T>(a[i]);          // y as it would have been stored
-}
-
-// MODE 0: per-workgroup partial sums {sum m, sum m * xhat} (m = dz where z > 0) -> partials[blockIdx.x][2][64]
-// MODE 1: filter-gradient slabs [blockIdx.x][64][9][CIN] from dy = ca * m + cb * y + ck (coefficients as uh_bn_relu_bwd_apply)
-template <typename T, int CIN, int MODE>
-__global__ __launch_bounds__(256, 2) void stem_bn_bwd_v3(const T* __restrict__ dz, int lddz, const T* __restrict__ x, int ldx,
-                                                      const T* __restrict__ w, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, const float* __restrict__ dgamma,
-                                                      const float* __restrict__ dbeta, float inv_n,
-                                                      float* __restrict__ out, int B, int H, int W, int tilesX, int tilesY) {
-    static_assert(sizeof(T) == 2, "the recomputed stem is the bf16 path");
-    constexpr int V = 8, COUT = 64;
-    __shared__ float xs[HALO_PIX * CIN];
-    __shared__ float red[4][MODE == 0 ? 2 : 9 * CIN][COUT];
-    const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;
-    const int ntile = B * tilesX * tilesY;
-    float wr[9 * CIN][V];
-#pragma unroll
-    for (int k = 0; k < 9 * CIN; ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) wr[k][i] = uh_to_f32(w[((int64_t)(g * V + i) * 9 + k / CIN) * CIN + (k % CIN)]);
-    // per-channel coefficients in LDS (read per pixel: with 72 taps + 72 accumulators in registers, 32 more would cost the
-    // second wave per SIMD): [0] = scale, [1] = shift, [2] / [3] = mean / rstd (MODE 0) or the dy coefficients b / k (MODE 1)
-    __shared__ __attribute__((aligned(16))) float cf[4][COUT];
-    if (tid < COUT) {
-        const float sc = scale[tid];
-        cf[0][tid] = sc;
-        cf[1][tid] = shift[tid];
-        if (MODE == 0) { cf[2][tid] = mean[tid]; cf[3][tid] = rstd[tid]; }
-        else {
-            const float b_ = -sc * rstd[tid] * dgamma[tid] * inv_n;
-            cf[2][tid] = b_;
-            cf[3][tid] = -sc * dbeta[tid] * inv_n - b_ * mean[tid];
-        }
-    }
-    float r_a[V], r_s[V], r_b[V], r_k[V];      // MODE 0 (2 x 8 accumulators only): the coefficients stay in registers
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-        const int c = g * V + i;
-        r_a[i] = MODE == 0 ? scale[c] : 0.f; r_s[i] = MODE == 0 ? shift[c] : 0.f;
-        r_b[i] = MODE == 0 ? mean[c] : 0.f; r_k[i] = MODE == 0 ? rstd[c] : 0.f;
-    }
-    float acc[MODE == 0 ? 2 : 9 * CIN][V];
-#pragma unroll
-    for (int k = 0; k < (MODE == 0 ? 2 : 9 * CIN); ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        int t = tile;
-        const int txt = t % tilesX; t /= tilesX;
-        const int tyt = t % tilesY;
-        const int b = t / tilesY;
-        const int y0 = tyt * TILE, x0p = txt * TILE;
-        const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
-        // the thread's eight 16-byte pieces of dz are requested first, branch-free, a rolling window of four in flight (see
-        // conv3x3_wgrad_stem_v3)
-        constexpr int DEPTH = MODE == 0 ? 4 : 2;
-        auto dz_piece = [&](int j) -> u32x4 {
-            const int px = pl + j * 32, tyc = min(px >> 4, vy - 1), txc = min(px & 15, vx - 1);
-            return *reinterpret_cast<const u32x4*>(dz + (int64_t)((b * H + y0 + tyc) * W + x0p + txc) * lddz + g * V);
-        };
-        u32x4 raw[DEPTH];
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) raw[j] = dz_piece(j);
-        __syncthreads();
-        for (int idx = tid; idx < HALO_PIX * CIN; idx += 256) {
-            int q = idx / CIN, ci = idx - q * CIN;
-            int hy = q / HALO_W, hx = q - hy * HALO_W;
-            int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = uh_to_f32(x[(int64_t)((b * H + gy) * W + gx) * ldx + ci]);
-            xs[idx] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int px = pl + j * 32, ty = px >> 4, tx = px & 15;
-            const bool in = ty < vy && tx < vx;
-            float d[V];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                d[2 * q] = in ? __builtin_bit_cast(float, raw[j % DEPTH][q] << 16) : 0.f;
-                d[2 * q + 1] = in ? __builtin_bit_cast(float, raw[j % DEPTH][q] & 0xffff0000u) : 0.f;
-            }
-            if (j + DEPTH < 8) raw[j % DEPTH] = dz_piece(j + DEPTH);
-            float yv[V];
-            stem_conv8<T, CIN>(xs, ty, tx, wr, yv);
-            float ca[V], cs[V], cb[V], ck[V];
-            if constexpr (MODE == 0) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) { ca[i] = r_a[i]; cs[i] = r_s[i]; cb[i] = r_b[i]; ck[i] = r_k[i]; }
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cf[0][g * V + 4 * h]), s4 = *reinterpret_cast<const f32x4*>(&cf[1][g * V + 4 * h]);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(&cf[2][g * V + 4 * h]), k4 = *reinterpret_cast<const f32x4*>(&cf[3][g * V + 4 * h]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ca[4 * h + e] = a4[e]; cs[4 * h + e] = s4[e]; cb[4 * h + e] = b4[e]; ck[4 * h + e] = k4[e]; }
-                }
-            }
-            if constexpr (MODE == 0) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    const float m = (fmaf(yv[i], ca[i], cs[i]) > 0.f) ? d[i] : 0.f;       // d is 0 outside the image
-                    acc[0][i] += m;
-                    acc[1][i] += m * (yv[i] - cb[i]) * ck[i];
-                }
-            } else {
-                float dyv[V];
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    const float m = (fmaf(yv[i], ca[i], cs[i]) > 0.f) ? d[i] : 0.f;
-                    const float o = uh_round_as<T>(fmaf(ca[i], m, fmaf(cb[i], yv[i], ck[i])));      // dy as it would have been stored
-                    dyv[i] = in ? o : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int ss = 0; ss < 3; ++ss)
-#pragma unroll
-                        for (int ci = 0; ci < CIN; ++ci) {
-                            const float xv = xs[((ty + r) * HALO_W + tx + ss) * CIN + ci];
-#pragma unroll
-                            for (int i = 0; i < V; ++i) acc[(r * 3 + ss) * CIN + ci][i] = fmaf(dyv[i], xv, acc[(r * 3 + ss) * CIN + ci][i]);
-                        }
-            }
-            if constexpr (MODE == 1) __builtin_amdgcn_sched_barrier(0);       // one pixel at a time: interleaving two costs the second wave per SIMD
-        }
-    }
-    constexpr int NK = MODE == 0 ? 2 : 9 * CIN;
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float v = acc[k][i];
-            for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-            acc[k][i] = v;
-        }
-    __syncthreads();
-    if ((tid & 63) < 8) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-            for (int i = 0; i < V; ++i) red[tid >> 6][k][g * V + i] = acc[k][i];
-    }
-    __syncthreads();
-    if constexpr (MODE == 0) {
-        for (int idx = tid; idx < 2 * COUT; idx += 256) {
-            const int k = idx / COUT, c = idx - k * COUT;
-            out[((int64_t)blockIdx.x * 2 + k) * COUT + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
-        }
-    } else {
-        float* slab = out + (int64_t)blockIdx.x * COUT * 9 * CIN;
-        for (int idx = tid; idx < 9 * CIN * COUT; idx += 256) {
-            const int k = idx / COUT, c = idx - k * COUT;
-            slab[((int64_t)c * 9 + k / CIN) * CIN + (k % CIN)] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
-        }
-    }
-}
-
 // ---- stem wgrad (Cin <= 4): lane = output channel; per-block partial [Cout][9][Cin]
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_stem(const T* __restrict__ dy, int lddy, const T* __restrict__ x,
@@ -3111,42 +2916,12 @@ extern "C" int uh_conv3x3_wgrad_pre(const void* dy, int lddy, const void* x0, in
                                           ws_bytes, B, H, W, (hipStream_t)stream, false, -1, -1, -1, pre_scale, pre_shift);
 }
 
-// ---- the stem with a recomputed output (see stem_bn_bwd_v3): Cin <= 4 -> 64 channels, bf16, w = KRSC pack [64][9][Cin]
-// (single-channel images: the backward-weights form keeps 9 * Cin * 8 taps AND as many accumulators per lane -- two waves per
-// SIMD at Cin = 1, spills from Cin = 2 on; an RGB stem costs 27 multiply-adds per element and keeps the stored path)
+// ---- the stem with a recomputed output (kernels: stem_mfma.hip): 1 -> 64 channels, bf16, w = KRSC pack [64][9][1]
+// (single-channel images: the conv is a GEMM with K = 9, one K = 16 MFMA; an RGB stem keeps the stored path)
 extern "C" int uh_stem_ok(int Cin, int Cout, int dt) { return (dt == UH_BF16 && Cin == 1 && Cout == 64) ? 1 : 0; }
 extern "C" int uh_stem_nblk(int B, int H, int W) {
     const int64_t ntile = (int64_t)B * ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
     return (int)(ntile < 1024 ? ntile : 1024);
-}
-
-template <int MODE>
-static int stem_bwd_launch(const bf16_t* dz, int lddz, const bf16_t* x, int Cin, int ldx, const bf16_t* w, const float* scale,
-                           const float* shift, const float* mean, const float* rstd, const float* dgamma, const float* dbeta,
-                           float inv_n, float* out, int B, int H, int W, hipStream_t st) {
-    const int tilesX = (W + TILE - 1) / TILE, tilesY = (H + TILE - 1) / TILE;
-    const int grid = uh_stem_nblk(B, H, W);
-    (void)Cin;      // uh_stem_ok: Cin == 1
-    hipLaunchKernelGGL((stem_bn_bwd_v3<bf16_t, 1, MODE>), dim3(grid), dim3(256), 0, st, dz, lddz, x, ldx, w, scale, shift, mean, rstd, dgamma, dbeta, inv_n, out, B, H, W, tilesX, tilesY);
-    return 0;
-}
-
-static int stem_fwd_launch(const bf16_t* x, int Cin, int ldx, const bf16_t* w, bf16_t* y, int ldy, float* stats, const float* sc,
-                           const float* sh, int B, int H, int W, hipStream_t st) {
-    const int tilesX = (W + TILE - 1) / TILE, tilesY = (H + TILE - 1) / TILE;
-    const int grid = uh_stem_nblk(B, H, W);
-    switch (Cin) {
-        case 1: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<bf16_t, 1>), dim3(grid), dim3(256), 0, st, x, ldx, w, y, ldy, stats, B, H, W, tilesX, tilesY, sc, sh, 1); break;
-        case 2: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<bf16_t, 2>), dim3(grid), dim3(256), 0, st, x, ldx, w, y, ldy, stats, B, H, W, tilesX, tilesY, sc, sh, 1); break;
-        case 3: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<bf16_t, 3>), dim3(grid), dim3(256), 0, st, x, ldx, w, y, ldy, stats, B, H, W, tilesX, tilesY, sc, sh, 1); break;
-        default: hipLaunchKernelGGL((conv3x3_fwd_stem_v3<bf16_t, 4>), dim3(grid), dim3(256), 0, st, x, ldx, w, y, ldy, stats, B, H, W, tilesX, tilesY, sc, sh, 1); break;
-    }
-    return 0;
-}
-
-static bool uh_stem_valu() {
-    static const bool on = getenv("UH_STEM_VALU") != nullptr;     // A/B: the serial-FMA recompute kernels instead of the MFMA ones
-    return on;
 }
 
 #define UH_STEM_COMMON(fn)                                                                                                    \
@@ -3159,12 +2934,8 @@ extern "C" int uh_stem_stats(const void* x, int Cin, int ldx, const void* w, flo
                              uh_stream stream) {
     UH_STEM_COMMON("uh_stem_stats");
     UH_REQUIRE(stat_partials, "uh_stem_stats: null statistics buffer");
-    if (!uh_stem_valu())
-        return uh_stem_mfma_launch(0, x, ldx, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0,
-                                   stat_partials, B, H, W, uh_stem_nblk(B, H, W), stream);
-    stem_fwd_launch((const bf16_t*)x, Cin, ldx, (const bf16_t*)w, nullptr, 64, stat_partials, nullptr, nullptr, B, H, W, (hipStream_t)stream);
-    UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3 (statistics only)");
-    return UH_OK;
+    return uh_stem_mfma_launch(0, x, ldx, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0,
+                               stat_partials, B, H, W, uh_stem_nblk(B, H, W), stream);
 }
 
 extern "C" int uh_stem_bn_relu_fwd(const void* x, int Cin, int ldx, const void* w, const float* scale, const float* shift, void* z,
@@ -3172,12 +2943,8 @@ extern "C" int uh_stem_bn_relu_fwd(const void* x, int Cin, int ldx, const void* 
     UH_STEM_COMMON("uh_stem_bn_relu_fwd");
     UH_REQUIRE(scale && shift && z && ldz >= 64, "uh_stem_bn_relu_fwd: null pointer / bad stride");
     UH_REQUIRE(uh_aligned16(z) && (ldz * 2) % 16 == 0, "uh_stem_bn_relu_fwd: z must be 16-byte aligned with a 16-byte pixel pitch");
-    if (!uh_stem_valu())
-        return uh_stem_mfma_launch(1, x, ldx, w, scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, z, ldz, nullptr,
-                                   B, H, W, uh_stem_nblk(B, H, W), stream);
-    stem_fwd_launch((const bf16_t*)x, Cin, ldx, (const bf16_t*)w, (bf16_t*)z, ldz, nullptr, scale, shift, B, H, W, (hipStream_t)stream);
-    UH_CHECK_LAUNCH("conv3x3_fwd_stem_v3 (BatchNorm + ReLU of the rounded output)");
-    return UH_OK;
+    return uh_stem_mfma_launch(1, x, ldx, w, scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, z, ldz, nullptr, B, H, W,
+                               uh_stem_nblk(B, H, W), stream);
 }
 
 extern "C" int uh_stem_bn_relu_bwd_reduce(const void* dz, int lddz, const void* x, int Cin, int ldx, const void* w,
@@ -3186,13 +2953,8 @@ extern "C" int uh_stem_bn_relu_bwd_reduce(const void* dz, int lddz, const void* 
     UH_STEM_COMMON("uh_stem_bn_relu_bwd_reduce");
     UH_REQUIRE(dz && scale && shift && mean && rstd && partials && lddz >= 64, "uh_stem_bn_relu_bwd_reduce: null pointer / bad stride");
     UH_REQUIRE(uh_aligned16(dz) && (lddz * 2) % 16 == 0, "uh_stem_bn_relu_bwd_reduce: dz must be 16-byte aligned with a 16-byte pixel pitch");
-    if (!uh_stem_valu())
-        return uh_stem_mfma_launch(2, x, ldx, w, scale, shift, mean, rstd, nullptr, nullptr, 0.f, dz, lddz, nullptr, 0, partials, B, H,
-                                   W, uh_stem_nblk(B, H, W), stream);
-    stem_bwd_launch<0>((const bf16_t*)dz, lddz, (const bf16_t*)x, Cin, ldx, (const bf16_t*)w, scale, shift, mean, rstd, nullptr,
-                       nullptr, 0.f, partials, B, H, W, (hipStream_t)stream);
-    UH_CHECK_LAUNCH("stem_bn_bwd_v3 (sums)");
-    return UH_OK;
+    return uh_stem_mfma_launch(2, x, ldx, w, scale, shift, mean, rstd, nullptr, nullptr, 0.f, dz, lddz, nullptr, 0, partials, B, H, W,
+                               uh_stem_nblk(B, H, W), stream);
 }
 
 extern "C" size_t uh_stem_bwd_wgrad_ws_bytes(int B, int H, int W, int Cin) {
@@ -3211,15 +2973,9 @@ extern "C" int uh_stem_bn_relu_bwd_wgrad(const void* dz, int lddz, const void* x
     hipStream_t st = (hipStream_t)stream;
     const float inv_n = (float)(1.0 / (double)(n_total > 0 ? n_total : (int64_t)B * H * W));
     float* slabs = (float*)ws;
-    if (!uh_stem_valu()) {
-        int rc = uh_stem_mfma_launch(3, x, ldx, w, scale, shift, mean, rstd, dgamma, dbeta, inv_n, dz, lddz, nullptr, 0, slabs, B, H, W,
-                                     uh_stem_nblk(B, H, W), stream);
-        if (rc != UH_OK) return rc;
-    } else {
-        stem_bwd_launch<1>((const bf16_t*)dz, lddz, (const bf16_t*)x, Cin, ldx, (const bf16_t*)w, scale, shift, mean, rstd, dgamma, dbeta,
-                           inv_n, slabs, B, H, W, st);
-        UH_CHECK_LAUNCH("stem_bn_bwd_v3 (filter gradient)");
-    }
+    const int rc = uh_stem_mfma_launch(3, x, ldx, w, scale, shift, mean, rstd, dgamma, dbeta, inv_n, dz, lddz, nullptr, 0, slabs, B, H, W,
+                                       uh_stem_nblk(B, H, W), stream);
+    if (rc != UH_OK) return rc;
     const int64_t n = (int64_t)64 * 9 * Cin;
     const int nsplit = uh_stem_nblk(B, H, W);
     if (n % 4 != 0 || !uh_aligned16(dw_krsc) || !uh_aligned16(slabs))
