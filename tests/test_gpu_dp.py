@@ -353,3 +353,51 @@ def test_bucketed_gradient_sync_runs_over_rccl_with_one_rank():
     (_, _, p, loss, nbuckets, nex), = _spawn(_rccl_one_rank_worker, world=1)
     assert nbuckets >= 1 and nex == 3
     assert loss == ref_loss and torch.equal(torch.from_numpy(p), ref_p)
+
+
+# ------------------------------------------------------------------------------------------ full-width bf16 under SyncBN
+def _fullwidth_syncbn_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import unet_amd
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=True, sync_bn=True)
+        im, mk = unet_amd.ellipse_batch(4, 64, seed=77)
+        lo, hi = rank * 2, rank * 2 + 2
+        t = None
+        for _ in range(2):
+            t = stepper.step(im[lo:hi].to(dev), mk[lo:hi].to(dev), global_batch=4)
+        torch.cuda.synchronize()
+        q.put((rank, "ok", stepper.optimizer.flat_p.cpu().numpy(), float(t["loss"]), float(t["bce"]), float(t["dice"])))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_full_width_bf16_step_under_sync_bn():
+    """The benchmarked model (full-width UNet, bf16: recomputed stem, pool / head tails) through the data-parallel SyncBN
+    path: both ranks end with bit-identical parameters (same global statistics, same all-reduced gradients) and their
+    global-batch BCE / Dice match the single-process step on the concatenated batch at bf16 tolerance."""
+    import unet_amd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+    st = unet_amd.TrainStepper(model, lr=1e-5, amp=True)
+    im, mk = unet_amd.ellipse_batch(4, 64, seed=77)
+    t = None
+    for _ in range(2):
+        t = st.step(im.to(dev), mk.to(dev))
+    torch.cuda.synchronize()
+    ref = (float(t["bce"]), float(t["dice"]))
+    st.optimizer.close()
+    res = _spawn(_fullwidth_syncbn_worker)
+    assert (res[0][2] == res[1][2]).all(), "ranks diverged"
+    for _, _, p, loss, bce, dice in res:
+        import numpy as np
+        assert np.isfinite(p).all() and np.isfinite(loss)
+        assert abs(bce - ref[0]) <= 3e-2 * abs(ref[0]) and abs(dice - ref[1]) <= 3e-2 * abs(ref[1]), ((bce, dice), ref)
