@@ -12,7 +12,7 @@ FAMILIES = [
     ("bn_relu_head_bwd_apply", r"bn_relu_head_bwd_apply_kernel"), ("bn_relu_head_bwd_reduce", r"bn_relu_head_bwd_reduce_kernel"),
     ("bn_relu_apply", r"bn_relu_apply_kernel"), ("bn_relu_bwd_apply", r"bn_relu_bwd_apply_kernel"), ("bn_relu_bwd_reduce", r"bn_relu_bwd_reduce_kernel"),
     ("maxpool2_fwd", r"maxpool2_fwd_kernel"), ("maxpool2_bwd", r"maxpool2_bwd_kernel"), ("upsample2x_fwd", r"upsample2x_fwd"),
-    ("upsample2x_bwd", r"upsample2x_bwd"), ("conv3x3_fwd_stem", r"conv3x3_fwd_stem"), ("conv3x3_wgrad_stem", r"conv3x3_wgrad_stem"),
+    ("upsample2x_bwd", r"upsample2x_bwd"), ("stem_recompute", r"stem_mfma_kernel"), ("conv3x3_fwd_stem", r"conv3x3_fwd_stem"), ("conv3x3_wgrad_stem", r"conv3x3_wgrad_stem"),
     ("conv1x1_fwd", r"conv1x1_fwd"), ("conv1x1_dgrad", r"conv1x1_dgrad_kernel"), ("conv1x1_wgrad", r"conv1x1_wgrad_kernel"),
     ("rmsprop", r"rmsprop_kernel"), ("grad_sumsq", r"grad_sumsq_kernel"), ("pack_w3x3_batched", r"pack_w3x3_batched_kernel"),
     ("bce_dice_sums", r"bce_dice_sums_kernel"), ("boundary_count", r"boundary_count_kernel"),
