@@ -276,12 +276,13 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a) {
                 }
             }
         };
+        // (MODE 2 / 3: one row at a time -- interleaving the four rows' unpacked values costs a wave per SIMD)
         do_row(std::integral_constant<int, 0>{});
-        if constexpr (MODE == 3) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE >= 2) __builtin_amdgcn_sched_barrier(0);
         do_row(std::integral_constant<int, 1>{});
-        if constexpr (MODE == 3) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE >= 2) __builtin_amdgcn_sched_barrier(0);
         do_row(std::integral_constant<int, 2>{});
-        if constexpr (MODE == 3) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE >= 2) __builtin_amdgcn_sched_barrier(0);
         do_row(std::integral_constant<int, 3>{});
         if constexpr (MODE == 0) {
             if (!have_pivot) {
