@@ -473,6 +473,35 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
         }
     };
     if constexpr (HOIST) coeffs((int)(first % G) * V);
+    if constexpr (HOIST && sizeof(T) == 2 && V == 8) {
+        // bf16, fixed channel group per thread: two pixels per trip, their four 16-byte pieces requested before the first is
+        // used (two in flight per lane before: 5.0 TB/s on the 805 MB layer)
+        const int c = (int)(first % G) * V;
+        const int64_t pstep = ((int64_t)gridDim.x * blockDim.x) / G;
+        for (int64_t p = first / G; p < npix; p += 2 * pstep) {
+            const int64_t p1 = p + pstep < npix ? p + pstep : p;
+            u32x4 rd[2], ry[2];
+            rd[0] = *reinterpret_cast<const u32x4*>(dz + p * lddz + c);
+            ry[0] = *reinterpret_cast<const u32x4*>(y + p * ldy + c);
+            rd[1] = *reinterpret_cast<const u32x4*>(dz + p1 * lddz + c);
+            ry[1] = *reinterpret_cast<const u32x4*>(y + p1 * ldy + c);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y0 = __uint_as_float(ry[u][e] << 16), y1 = __uint_as_float(ry[u][e] & 0xffff0000u);
+                    const float d0 = __uint_as_float(rd[u][e] << 16), d1 = __uint_as_float(rd[u][e] & 0xffff0000u);
+                    const float m0 = (fmaf(y0, ca[2 * e], cs[2 * e]) > 0.f) ? d0 : 0.f;
+                    const float m1 = (fmaf(y1, ca[2 * e + 1], cs[2 * e + 1]) > 0.f) ? d1 : 0.f;
+                    o[2 * e] = fmaf(ca[2 * e], m0, fmaf(cb[2 * e], y0, ck[2 * e]));
+                    o[2 * e + 1] = fmaf(ca[2 * e + 1], m1, fmaf(cb[2 * e + 1], y1, ck[2 * e + 1]));
+                }
+                if (u == 0 || p + pstep < npix) uh_store<T, V>(dy + (u == 0 ? p : p1) * lddy + c, o);
+            }
+        }
+        return;
+    }
     for (int64_t idx = first; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int64_t p = idx / G;
         int c = (int)(idx - p * G) * V;
