@@ -445,7 +445,7 @@ def test_train_step_is_bit_deterministic(ctor, bilinear, amp):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
-@pytest.mark.parametrize("ctor,bilinear,amp", [("UNet_T", True, False), ("UNet_S", False, True)])
+@pytest.mark.parametrize("ctor,bilinear,amp", [("UNet_T", True, False), ("UNet_S", False, True), ("UNet", True, True)])
 def test_graph_captured_step_matches_eager(ctor, bilinear, amp):
     """GraphedTrainStepper (the whole step replayed from a HIP graph) == TrainStepper, bit for bit, including the BatchNorm
     buffers; the capture's warm-up steps must not count as training; a NaN batch raises and leaves the weights alone."""
