@@ -61,6 +61,7 @@ def parse():
                     help="BASELINE config 4: 5-level UNet (64..2048/2), 3x1024x1024 in, 4 classes, bilinear (use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="one GPU: replay the whole step from a captured HIP graph (GraphedTrainStepper)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the global-batch-32 leg (strong_gb32)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
     ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg")
@@ -268,8 +269,15 @@ def main():
         model = unet_amd.UNet(1, 1, bilinear=bilinear)
     model = model.to(memory_format=torch.channels_last).to(dev)
     amp = not args.fp32
-    stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=args.side_stream and not args.no_side_stream, cc_loss=args.cc_loss,
-                                   fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
+    if args.graph:
+        if world > 1 or args.cc_loss:
+            raise SystemExit("--graph is a single-GPU option without --cc-loss")
+        stepper = unet_amd.GraphedTrainStepper(model, lr=1e-5, amp=amp, fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact",
+                                               check_nan=os.environ.get("UH_GRAPH_NO_NAN_CHECK") != "1")
+        args.no_kernel_profile = True          # per-launch events cannot be recorded inside a replayed graph
+    else:
+        stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=args.side_stream and not args.no_side_stream, cc_loss=args.cc_loss,
+                                       fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
     strong = args.global_batch > 0
     if strong:
         if args.global_batch % world:
@@ -291,6 +299,8 @@ def main():
 
     def run_step(im, mk):
         # equal shards: the global batch is known without asking the other ranks (saves SyncBN's blocking host read per step)
+        if args.graph:
+            return stepper.step(im, mk)
         return stepper.step(im, mk, global_batch=int(im.shape[0]) * world if args.sync_bn else None)
 
     def measure(im, mk, steps: int, warmup: int):
