@@ -320,6 +320,11 @@ int uh_dice_sums(const float* x, const float* t, int64_t ngroups, int64_t group_
 int uh_boundary_loss(const float* pred, int64_t pstride, int64_t bstride, const float* target, int B, int H, int W,
                      int edge_width, float edge_weight, float smooth, float* out,
                      void* ws, size_t ws_bytes, uh_stream stream);
+/* The same with the target given as the int64 class-index mask and a divisor, target = mask / mask_div (train.py:119 `true_masks
+ * //= 2` feeding train.py:134): no float copy of the mask is made. */
+int uh_boundary_loss_mask(const float* pred, int64_t pstride, int64_t bstride, const int64_t* mask, int mask_div, int B, int H,
+                          int W, int edge_width, float edge_weight, float smooth, float* out, void* ws, size_t ws_bytes,
+                          uh_stream stream);
 
 /* ---- clip_grad_norm_ + RMSprop  (train.py:80-81,157-158) -----------------------------------
  * Flat-buffer form: all parameters / gradients / optimizer states live in four equally laid out

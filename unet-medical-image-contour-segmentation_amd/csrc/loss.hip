@@ -356,8 +356,11 @@ __global__ __launch_bounds__(256) void boundary_minmax_kernel(const float* __res
     }
 }
 
+// target: float [B][H][W], or (mask != NULL) the int64 class-index mask itself with target = mask / mask_div -- what
+// train.py:119 / 134 hands to boundary_loss -- so that no float copy of the mask has to be made
 __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __restrict__ pred, int64_t pstride, int64_t bstride,
-                                                             const float* __restrict__ target, int B, BRegion g,
+                                                             const float* __restrict__ target, const int64_t* __restrict__ mask,
+                                                             int mask_div, int B, BRegion g,
                                                              const float* __restrict__ mm, int nmm,
                                                              float* __restrict__ partials) {
     // global min / max of the prediction from the <= 512 partial pairs, by the whole block (one thread walking them was
@@ -382,7 +385,10 @@ __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __rest
         if (sig) v = 1.f / (1.f + expf(-v));
         return v > 0.5f ? 1.f : 0.f;
     };
-    auto tbin = [&](int64_t b, int r) -> float { return target[b * HW + r] == 255.f ? 1.f : 0.f; };   // boundary_loss.py:37
+    auto tbin = [&](int64_t b, int r) -> float {                                                      // boundary_loss.py:37
+        if (mask) return (float)(mask[b * HW + r] / mask_div) == 255.f ? 1.f : 0.f;
+        return target[b * HW + r] == 255.f ? 1.f : 0.f;
+    };
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // {inter, psum, tsum} x {interior, edge}
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t b = i / HW;
@@ -433,9 +439,27 @@ __global__ __launch_bounds__(256) void boundary_finish_kernel(const float* __res
     out[0] = (normal + edge_weight * edge) / (1.f + edge_weight);     // boundary_loss.py:44
 }
 
+static int boundary_loss_impl(const float* pred, int64_t pstride, int64_t bstride, const float* target, const int64_t* mask,
+                              int mask_div, int B, int H, int W, int edge_width, float edge_weight, float smooth, float* out,
+                              void* ws, size_t ws_bytes, uh_stream stream);
+
 extern "C" int uh_boundary_loss(const float* pred, int64_t pstride, int64_t bstride, const float* target, int B, int H, int W, int edge_width,
                                 float edge_weight, float smooth, float* out, void* ws, size_t ws_bytes, uh_stream stream) {
-    UH_REQUIRE(pred && target && out && ws && B > 0 && H > 0 && W > 0 && pstride > 0 && edge_width >= 0,
+    UH_REQUIRE(target, "uh_boundary_loss: null target");
+    return boundary_loss_impl(pred, pstride, bstride, target, nullptr, 1, B, H, W, edge_width, edge_weight, smooth, out, ws, ws_bytes, stream);
+}
+
+extern "C" int uh_boundary_loss_mask(const float* pred, int64_t pstride, int64_t bstride, const int64_t* mask, int mask_div, int B,
+                                     int H, int W, int edge_width, float edge_weight, float smooth, float* out, void* ws,
+                                     size_t ws_bytes, uh_stream stream) {
+    UH_REQUIRE(mask && mask_div >= 1, "uh_boundary_loss_mask: null mask / bad divisor");
+    return boundary_loss_impl(pred, pstride, bstride, nullptr, mask, mask_div, B, H, W, edge_width, edge_weight, smooth, out, ws, ws_bytes, stream);
+}
+
+static int boundary_loss_impl(const float* pred, int64_t pstride, int64_t bstride, const float* target, const int64_t* mask,
+                              int mask_div, int B, int H, int W, int edge_width, float edge_weight, float smooth, float* out,
+                              void* ws, size_t ws_bytes, uh_stream stream) {
+    UH_REQUIRE(pred && (target || mask) && out && ws && B > 0 && H > 0 && W > 0 && pstride > 0 && edge_width >= 0,
                "uh_boundary_loss: bad args");
     UH_REQUIRE(bstride > 0, "uh_boundary_loss: bad batch stride");
     UH_REQUIRE(ws_bytes >= uh_loss_ws_bytes((int64_t)B * H * W), "uh_boundary_loss: workspace too small");
@@ -450,7 +474,7 @@ extern "C" int uh_boundary_loss(const float* pred, int64_t pstride, int64_t bstr
     int nmm = nblk < 512 ? nblk : 512;
     hipLaunchKernelGGL(boundary_minmax_kernel, dim3(nmm), dim3(256), 0, st, pred, pstride, n, H * W, bstride, mmbuf);
     UH_CHECK_LAUNCH("boundary_minmax_kernel");
-    hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, B, g,
+    hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, mask, mask_div, B, g,
                        (const float*)mmbuf, nmm, partials);
     UH_CHECK_LAUNCH("boundary_count_kernel");
     hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, B, g, edge_weight,

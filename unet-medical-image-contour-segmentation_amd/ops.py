@@ -1329,8 +1329,10 @@ class SegLossBinaryFn(Function):
             reduce_sums(sums)
         bl = None
         if w_boundary != 0.0:
-            tf = (mk // mask_div).float() if mask_div != 1 else mk.float()
-            bl = boundary_loss_value(lg, 1, H * W, tf, B, H, W, edge_width, edge_weight)
+            # boundary_loss(logits, (mask // mask_div).float(), 51, 15), train.py:134 -- the kernel divides the int64 mask itself
+            bl = torch.empty(1, dtype=torch.float32, device=dev)
+            LIB.call("uh_boundary_loss_mask", lg.data_ptr(), 1, H * W, mk.data_ptr(), int(mask_div), B, H, W, int(edge_width),
+                     float(edge_weight), 1e-6, bl.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         out = torch.empty(4, dtype=torch.float32, device=dev)
         LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(round(n * world)), _p(bl), float(w_boundary),
                  out.data_ptr(), _stream())
