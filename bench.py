@@ -362,7 +362,7 @@ def main():
         ops.PROFILE_ON = False
     if rank == 0 and not args.no_kernel_profile:
         agg = {}
-        for name, flops, e0, e1 in ops.PROFILE:
+        for name, flops, e0, e1, _tag in ops.PROFILE:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -397,6 +397,31 @@ def main():
             kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
         except Exception as e:                      # an optional extra must never cost the headline line
             kernels["double_conv_256"] = {"error": repr(e)}
+        # ... and the same six launches where they run in the timed workload: down2 of the profiled train step above (events
+        # around each launch, backward-weights including its slab reduction, the BatchNorm / pooling kernels of the step
+        # between them instead of twenty launches of one kernel back to back)
+        try:
+            q = S // 4
+            want = {"fwd_conv1": ("fwd", B, q, q, 128, 256), "fwd_conv2": ("fwd", B, q, q, 256, 256),
+                    "dgrad_conv2": ("dgrad", B, q, q, 256, 256), "dgrad_conv1": ("dgrad", B, q, q, 256, 128),
+                    "wgrad_conv2": ("wgrad", B, q, q, 256, 256), "wgrad_conv1": ("wgrad", B, q, q, 128, 256)}
+            ins, tot_s, tot_f = {}, 0.0, 0.0
+            for key, tag in want.items():
+                # up2.3 (256 -> 128 at this extent) is a forward launch WITH statistics: the tag's direction tells it from
+                # down2's backward-data; the first match in launch order is down2's for every other key
+                hits = [(f, e0.elapsed_time(e1) * 1e-3) for _n, f, e0, e1, t in ops.PROFILE if t == tag]
+                if len(hits) != 1:
+                    raise RuntimeError(f"{key}: {len(hits)} launches tagged {tag}")
+                f, sec = hits[0]
+                ins[key] = {"ms": round(sec * 1e3, 4), "tflops": round(f / sec / 1e12, 1)}
+                tot_s += sec
+                tot_f += f
+            ins["all_six"] = {"ms": round(tot_s * 1e3, 4), "tflops": round(tot_f / tot_s / 1e12, 1)}
+            ins["what"] = "one launch each, inside the profiled train step (single events pair per launch)"
+            if amp and bilinear and not args.config4 and n_in == 1:
+                kernels["double_conv_256_in_step"] = ins
+        except Exception as e:
+            kernels["double_conv_256_in_step"] = {"error": repr(e)}
         # the same six kernels at the extent the layer has in BASELINE config 3's global batch (32 images): eight tiles per
         # resident workgroup instead of two, the 75 MB of backward-weights slabs amortised over 4x the pixels
         if amp and B == 8 and S == 512 and not args.config4:

@@ -83,6 +83,19 @@ int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout, int ld0, 
 int uh_conv3x3_fwd(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                    const void* w, void* y, int ldy, int Cout, float* stat_partials,
                    int B, int H, int W, int dt, uh_stream stream);
+/* Backward-data of the SECOND conv of a DoubleConv fused with the first pass of the BatchNorm backward of the layer in front of it
+ * (unet_parts.py:15-20 differentiated).  The launch computes dx = conv(dy, w_dgrad) as uh_conv3x3_fwd
+ * does -- dx is the gradient of z = ReLU(BatchNorm(q)), q [B,H,W,Cdx] the raw output of the first conv -- and, from its
+ * accumulators (rounded to bf16 as stored) and one read of q, the per-workgroup partial sums
+ *     partials[row][0][c] = sum_p g,   partials[row][1][c] = sum_p g * (q - mean[c]) * rstd[c],    g = dx where q*scale+shift > 0 else 0
+ * in the [nblk][2][C] layout uh_bn_relu_bwd_apply / uh_bn_bwd_finalize take: uh_bn_relu_bwd_reduce (a read of dx and of q) is not
+ * launched for that layer.  coef = [scale | shift | mean | rstd], Cdx floats each (what uh_bn_finalize produced in the forward).
+ * bf16, MFMA-aligned single-source shapes below 2 GiB, ldq == lddx: uh_conv3x3_dgrad_bnsum_rows() returns the number of partial rows the
+ * call writes (nblk), or 0 when the shape must take the two separate kernels.  dt may carry UH_WFRAG (pack of w_dgrad). */
+int uh_conv3x3_dgrad_bnsum_rows(int B, int H, int W, int Cdy, int Cdx, int lddy, int lddx, int ldq, int dt);
+int uh_conv3x3_dgrad_bnsum(const void* dy, int Cdy, int lddy, const void* w_dgrad, void* dx, int lddx, int Cdx,
+                           const void* q, int ldq, const float* coef, float* partials,
+                           int B, int H, int W, int dt, uh_stream stream);
 /* The stem of the network with a RECOMPUTED output (inc.double_conv.0-2: Conv2d(1 -> 64) -> BatchNorm2d -> ReLU on a
  * single-channel image, unet_parts.py:15-17; unet_model.py:15): the conv output y costs 9 multiply-adds per element and is the
  * largest tensor of the model, so it is never stored -- every consumer rebuilds it from the image on the matrix pipe (a GEMM

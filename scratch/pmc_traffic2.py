@@ -6,6 +6,9 @@ import collections, csv, glob, hashlib, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = [
+    # backward-data launches that also form BatchNorm-backward sums (last template argument of conv3x3_fwd_mfma_v2, mangled or not):
+    # a family of their own, like in bench.py's kernel profile -- they read one more tensor than the plain kernel
+    ("conv3x3_dgrad_bnsum_mfma", r"conv3x3_fwd_mfma_v2I\w+?ELb1EEvPKT|conv3x3_fwd_mfma_v2<[^>]*true>"),
     ("conv3x3_fwd_mfma", r"conv3x3_fwd_mfma_v2"), ("conv3x3_wgrad_mfma", r"conv3x3_wgrad_mfma_v2"), ("slab_reduce", r"slab_reduce_kernel"),
     ("bn_relu_pool_apply", r"bn_relu_pool_apply_kernel"), ("bn_relu_pool_bwd_apply", r"bn_relu_pool_bwd_apply_kernel"),
     ("bn_relu_pool_bwd_reduce", r"bn_relu_pool_bwd_reduce_kernel"), ("bn_relu_head_fwd", r"bn_relu_head_fwd_kernel"),
@@ -80,7 +83,7 @@ def main():
                         "algorithmic bytes on the layers that dominate the traffic).",
         "source_sha256": sha, "families": fams, "conv_layers": table,
     }
-    for fam in ("conv3x3_fwd_mfma", "conv3x3_wgrad_mfma"):
+    for fam in ("conv3x3_fwd_mfma", "conv3x3_dgrad_bnsum_mfma", "conv3x3_wgrad_mfma"):
         if fam in fams:
             out[fam + "_per_launch"] = {"hbm_MB": round(fams[fam]["fetch_MB_per_launch_raw"] + fams[fam]["write_MB_per_launch"], 1)}
     tot = sum(v["launches_per_step"] * ((v["fetch_MB_per_launch_raw"] if k.startswith("conv3x3") and "mfma" in k else v["fetch_MB_per_launch_x2"]) + v["write_MB_per_launch"])

@@ -100,8 +100,9 @@ def test_train_step_with_and_without_the_fused_input(model_name, size):
     mk = torch.randint(0, 3, (2, size, size), generator=g).to(dev)
     out = {}
     calls = {}
-    default, default_stem = ops.FUSE_PRE, ops.STEM_RECOMPUTE
+    default, default_stem, default_bnsum = ops.FUSE_PRE, ops.STEM_RECOMPUTE, ops.FUSE_BNSUM
     ops.STEM_RECOMPUTE = False       # (the recomputed stem sums its BatchNorm-backward partials in another order: not bit-comparable)
+    ops.FUSE_BNSUM = False           # (so do the sums formed inside backward-data, which only the stored-activation leg would take)
     for fuse in (False, True):
         ops.FUSE_PRE = fuse
         try:
@@ -121,6 +122,7 @@ def test_train_step_with_and_without_the_fused_input(model_name, size):
             ops.FUSE_PRE = default
             if fuse:
                 ops.STEM_RECOMPUTE = default_stem
+                ops.FUSE_BNSUM = default_bnsum
     a, b = out[False], out[True]
     assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"] and a["gn"] == b["gn"]
     assert torch.equal(a["g"], b["g"]) and torch.equal(a["p"], b["p"])

@@ -548,15 +548,33 @@ __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }
 // halo tile still travels HBM -> LDS by DMA; once a wave's own pieces have landed (its covering vmcnt) every thread rewrites
 // the pieces IT issued in place (ds_read_b128 -> 8 x fma / max -> ds_write_b128) in front of the chunk's barrier.  Pieces
 // outside the image stay zero (the padding of the ACTIVATION is zero, not max(shift, 0)).  The 2 * C0 coefficients sit in LDS.
+// BSUM (bf16 backward-data of the SECOND conv of a DoubleConv): the tensor this launch produces is dz, the gradient of the
+// activation z = ReLU(BatchNorm(q)) between the two convs (q = bs_y: the first conv's raw output, same shape as this launch's
+// output).  The two per-channel sums BatchNorm's backward starts with (unet_parts.py:16-17 differentiated)
+//     sum_p g,   sum_p g * (q - mean) * rstd        with g = dz where q * scale + shift > 0, else 0
+// are formed in this kernel's epilogue from the accumulators (rounded to bf16 as stored) and one read of q, like the forward's
+// statistics: one partial row per workgroup, [row][2][Cout] -- the layout uh_bn_bwd_finalize / uh_bn_relu_bwd_apply take.  The
+// uh_bn_relu_bwd_reduce pass (a read of dz and of q) is not launched for that layer.
 constexpr int PRE_MAX_C = 512;
-template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false>
+template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false, bool BSUM = false>
 __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
     const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int C0v, int C1v, int Coutv, int wfrag,
-    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
+    const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr,
+    const T* __restrict__ bs_y = nullptr, int bs_ld = 0, unsigned bs_bytes = 0, const float* __restrict__ bs_coef = nullptr) {
     static_assert(!PRE || (sizeof(T) == 2 && !SPLIT), "PRE is the bf16 training path");
+    static_assert(!BSUM || (sizeof(T) == 2 && !SPLIT && !PRE), "BSUM is the bf16 backward-data path");
+    if constexpr (BSUM) {
+        // a plain single-source call (the host checks it): folding the second source, the narrow-tensor counts and the inference
+        // epilogue away frees the scalar registers the extra arguments take -- the scalar file is full (the base kernel already
+        // parks scalars in vector lanes), and every parked scalar costs the MFMA loop a vector register
+        x1 = nullptr; C1 = 0; ld1 = 0; x1_bytes = 0;
+        C0v = C0; C1v = 0; Coutv = Cout;
+        ep_scale = nullptr; ep_shift = nullptr;
+        bs_ld = ldy; bs_bytes = y_bytes;            // q has the geometry of the tensor this launch writes
+    }
     // C0 / C1 / Cout are the channel counts the filter pack is laid out for (multiples of a chunk / of 64); C0v / C1v /
     // Coutv (<=) are the channels that exist in memory ("narrow" tensors of the small-width nets): input channels
     // beyond them are fetched as zeros by the DMA, output channels beyond Coutv are computed (zero filters) but not stored.
@@ -577,6 +595,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
     __shared__ float wg_sum[3][BN];          // [0] = S1, [1] = S2, [2] = pivot; slot = channel - co_blk
     __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * PRE_MAX_C : 4];     // PRE: (scale, shift) pairs of source 0
+    __shared__ __attribute__((aligned(16))) float bs_tab[BSUM ? 4 * BN : 4];            // BSUM: [scale | shift | mean | rstd][slot]
     float n_run = 0.f;
 
     const int tid = threadIdx.x;
@@ -616,13 +635,17 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     const u32x4 rs1 = uh_desc_words(x1 ? x1 : x0, x1 ? x1_bytes : x0_bytes);
     __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)y_bytes, 0x00020000);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // (BSUM with 128 accumulators: six registers too many -- the offsets are rebuilt at every issue, ~30 VALU operations per chunk
+    // of 288 MFMAs, from an opaque copy of the thread id so that they are not hoisted back out of the loop)
+    constexpr bool REL_LIVE = !(BSUM && NBW == 2);
+    auto rel_of = [&](int t, int k) -> int {
+        const int p = t + k * 256, q = p >> 2;
+        const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;          // q / 18 for q < 324
+        return (hy * W + hx) * ld0 * ES + (((p & 3) ^ halo_swz(hx)) << 4);
+    };
     int rel0[NLOAD];
 #pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        const int p = tid + k * 256, q = p >> 2;
-        const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;          // q / 18 for q < 324
-        rel0[k] = (hy * W + hx) * ld0 * ES + (((p & 3) ^ halo_swz(hx)) << 4);
-    }
+    for (int k = 0; k < NLOAD; ++k) rel0[k] = REL_LIVE ? rel_of(tid, k) : 0;
     // tile the NEXT DMA reads from (scalars): image, top-left pixel, "halo inside the image"
     int d_b = 0, d_y0 = 0, d_x0 = 0;
     bool d_in = false;
@@ -651,8 +674,10 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             for (int k = 0; k < NLOAD; ++k) voff[k] = OOB_OFFSET;
         } else if (ld == ld0 && cleft >= CK) {
             if (d_in) {
+                int tid_r = tid;
+                if constexpr (!REL_LIVE) asm volatile("" : "+v"(tid_r));
 #pragma unroll
-                for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)(rel0[k] + base);
+                for (int k = 0; k < NLOAD; ++k) voff[k] = (unsigned)((REL_LIVE ? rel0[k] : rel_of(tid_r, k)) + base);
                 if (tid + (NLOAD - 1) * 256 >= NPIECE) voff[NLOAD - 1] = OOB_OFFSET;
             } else {
                 // (the opaque copy of tid keeps the per-slot coordinates from being hoisted out of the tile loop into 12
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                     const int q = (tid_o + k * 256) >> 2;
                     const int hy = (q * 3641) >> 16, hx = q - hy * HALO_W;
                     const bool ok = (unsigned)(d_y0 - 1 + hy) < (unsigned)H && (unsigned)(d_x0 - 1 + hx) < (unsigned)W && q < HALO_PIX;
-                    voff[k] = ok ? (unsigned)(rel0[k] + base) : OOB_OFFSET;
+                    voff[k] = ok ? (unsigned)((REL_LIVE ? rel0[k] : rel_of(tid_o, k)) + base) : OOB_OFFSET;
                 }
             }
         } else {
@@ -835,7 +860,9 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     auto mma_shift = [&](const unsigned char* buf, int sft, auto&& wget) {       // wget(r, n): filter fragment of row tap r, MFMA n
         u32x4 xf[18];
         // column-only swizzle: the lane part of the address is the same for all 18 rows (immediate offsets)
-        const unsigned char* xcol = buf + (lx + sft) * 64 + ((kg ^ halo_swz(lx + sft)) << 4);
+        int lq = lane;
+        if constexpr (!REL_LIVE) asm volatile("" : "+v"(lq));       // (same register shortage: the three column offsets are not kept either)
+        const unsigned char* xcol = buf + ((lq & 15) + sft) * 64 + (((lq >> 4) ^ halo_swz((lq & 15) + sft)) << 4);
         auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
 #pragma unroll
         for (int k = 0; k < 2 + PF; ++k) xf[k] = rd(k);
@@ -897,6 +924,13 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         // the coefficient table must be complete before the first rewrite: one extra barrier, once per kernel
         for (int i = tid; i < C0; i += 256) { pre_tab[2 * i] = pre_scale[i]; pre_tab[2 * i + 1] = pre_shift[i]; }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (BSUM) {
+        // this workgroup's BN channels of [scale | shift | mean | rstd] (Cout entries each); first read in the first epilogue,
+        // behind the barriers of the chunk fences
+        for (int i = tid; i < 4 * BN; i += 256) bs_tab[i] = bs_coef[(i / BN) * Cout + co_blk + (i % BN)];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
     chunk_fence(chunk_of(0), 0, true);
@@ -966,6 +1000,33 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         const int gx = x0p + lx;
         const int vy = min(TILE, H - y0), vx = min(TILE, W - x0p);
         const bool full = (vy == TILE) && (vx == TILE);          // wave-uniform: interior tiles take the mask-free path
+        // BSUM: the 16 x NBW eight-byte pieces of q this lane's accumulators meet (pixel (row i, column lx), channels ch(kg, n, 0..3))
+        // come in batches of eight rows (16 registers), two batches in flight: the next one is always requested before the
+        // previous one is summed.  The sums run BEFORE the stores: behind them hipcc kept the packed bf16 halves of the store data
+        // alive beside the values the sums need.  The kernel runs at the register limit: all 32 x NBW
+        // registers at once spilled the DMA offsets / filter fragments into the MFMA loop (the ISA lint refuses that), and the
+        // lane constants of this block are rebuilt per tile from an opaque copy of the lane id instead of living through the loop.
+        constexpr int BQB = 2 * NBW;                   // batches: (n, row half)
+        u32x2 bqA[BSUM ? 8 : 1], bqB[BSUM ? 8 : 1];
+        int lane_o = lane;
+        if constexpr (BSUM) asm volatile("" : "+v"(lane_o));
+        const int lx_o = lane_o & 15, kg_o = lane_o >> 4;
+        auto bq_load = [&](u32x2 (&dst)[BSUM ? 8 : 1], int bi) {
+            if constexpr (BSUM) {
+                __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)bs_y, 0, (int)bs_bytes, 0x00020000);
+                const int n = bi >> 1, i0 = (bi & 1) * 8;
+                // every request stays inside the image (row / column clamped: what a clamped request returns meets an accumulator
+                // that was set to zero above); the row part of the address is wave-uniform and rides in the scalar offset operand --
+                // sixteen per-row vector offsets would live from here through the stores (hipcc shares them: same pitch)
+                const int gxc = min(x0p + (lane_o & 15), W - 1);
+                const unsigned voff = (unsigned)((gxc * bs_ld + co_blk + ch(lane_o >> 4, n, 0)) * ES);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = min(i0 + i, vy - 1);
+                    dst[i] = __builtin_amdgcn_raw_buffer_load_b64(rsq, voff, ((b * H + y0 + r) * W) * bs_ld * ES, 0);
+                }
+            }
+        };
         if (ep_scale) {      // inference: eval-mode BatchNorm (per-channel scale/shift) + ReLU applied to the accumulators
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
@@ -984,6 +1045,94 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][n][j] = uh_round_as<T>(acc[i][n][j]);
+        // (BSUM: the rounded fp32 values REPLACE the accumulators here; left to its own schedule hipcc kept the packed bf16 halves
+        // for the stores beside the fp32 originals for the sums -- 128 more registers, spilled)
+        if constexpr (BSUM) __builtin_amdgcn_sched_barrier(0);
+
+        if constexpr (BSUM) {
+            float* S1 = &wg_sum[0][0];
+            float* S2 = &wg_sum[1][0];
+            if (tile == tile_lane && lx_o == 0) {        // the workgroup's first tile
+#pragma unroll
+                for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { S1[ch(kg_o, n, j)] = 0.f; S2[ch(kg_o, n, j)] = 0.f; }
+            }
+            if (!full) {
+                // border tile: the accumulators of pixels outside the image (never stored) must not reach the sums
+                const bool inw = x0p + lx_o < W;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][n][j] = (i < vy && inw) ? acc[i][n][j] : 0.f;
+            }
+            constexpr bool BQ2 = NBW == 1;              // two batches in flight (NBW = 2: one at a time -- no time difference in an A/B of the three schedules, fewest spills)
+            if constexpr (BQ2) bq_load(bqA, 0);
+            float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};
+            auto bq_sum = [&](const u32x2 (&src)[8], int bi) {
+                const int n = bi >> 1, i0 = (bi & 1) * 8;
+                const int c0 = ch(kg_o, n, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sc = bs_tab[0 * BN + c0 + j], sh = bs_tab[1 * BN + c0 + j], mu = bs_tab[2 * BN + c0 + j];
+                    float s1 = (bi & 1) ? p1[j] : 0.f, s2 = (bi & 1) ? p2[j] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned pk = src[i][j >> 1];
+                        const float qv = __uint_as_float((j & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                        const bool on = fmaf(qv, sc, sh) > 0.f;                  // the ReLU mask, as uh_bn_relu_apply decided it
+                        const float g = on ? acc[i0 + i][n][j] : 0.f;            // acc: already rounded to the stored type
+                        s1 += g;
+                        s2 = fmaf(g, qv - mu, s2);
+                    }
+                    if (bi & 1) {
+                        const float a1 = uh_row16_sum(s1), a2 = uh_row16_sum(s2);
+                        if (lx_o == 0) {
+                            S1[c0 + j] += a1;
+                            S2[c0 + j] += a2;
+                        }
+                    } else {
+                        p1[j] = s1;
+                        p2[j] = s2;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // one channel at a time (left free, the scheduler interleaves all four: +40 registers)
+                }
+            };
+#pragma unroll
+            for (int bi = 0; bi < BQB; ++bi) {
+                // request batch bi + 1, then sum batch bi (even batches sit in bqA, odd ones in bqB)
+                if constexpr (BQ2) {
+                    if (bi + 1 < BQB) {
+                        if (bi & 1) bq_load(bqA, bi + 1); else bq_load(bqB, bi + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (bi & 1) bq_sum(bqB, bi); else bq_sum(bqA, bi);
+                } else {
+                    bq_load(bqA, bi);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bq_sum(bqA, bi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // batch boundary, enforced: hipcc otherwise runs the sums channel-major over BOTH row halves (the partial sums
+                // chain them), i.e. with two batches of q and all twelve coefficients in registers.  The partial sums pass through
+                // an opaque statement, and the next request's address depends on an opaque copy made behind it.
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(p1[j]), "+v"(p2[j]));
+                asm volatile("" : "+v"(lane_o));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // The stores below convert the (already rounded) values to bf16 a second time.  hipcc knows that this is the
+            // conversion the rounding made and keeps its 128 packed results alive from there to here, beside the 128 fp32 values
+            // the sums read: opaque copies make it convert again (two registers at a time).
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][n][j]));
+        }
 
         // ---- stores, straight from the registers through a buffer descriptor: per-lane byte offset (column, channel
         // piece; out of range for columns / channels that do not exist, which drops the store) + the row offset.  The row
@@ -1048,23 +1197,25 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
 
         // ---- BatchNorm statistics: pivot-shifted sums per lane, 4 DPP adds per channel, accumulated in LDS by the lane that
         // owns the channel's slot (the same lane every tile: no barrier, a wave only touches its own channels)
-        if (stats) {
+        if (!BSUM && stats) {
             float* S1 = &wg_sum[0][0];          // slot = channel - co_blk: a wave touches its own channels only
             float* S2 = &wg_sum[1][0];
             float* PV = &wg_sum[2][0];
             if (n_run == 0.f) {
-                // pivot = one stored value of each channel from the MIDDLE of the workgroup's first tile (pixel (8,8); (0,0) only
-                // when the tile is that small).  The first tile of workgroup 0 is the image corner, where zero padding makes
-                // pixel (0,0) the least typical value of a channel: on a near-constant channel (flat background) a corner pivot
-                // costs eps * (corner - level)^2 of noise per pixel in S2 - S1^2 / n, an interior one costs nothing.
-                const bool mid_r = vy > 8, mid_c = vx > 8;                    // wave-uniform
-                if (lx == (mid_c ? 8 : 0)) {
+                // pivot = one value of each channel from INSIDE the workgroup's first tile (pixel (2,8); column 0 only when the
+                // tile is that narrow).  The first tile of workgroup 0 is the image corner, where zero padding makes pixel (0,0)
+                // the least typical value of a channel: on a near-constant channel (flat background) a corner pivot costs
+                // eps * (corner - level)^2 of noise per pixel in S2 - S1^2 / n, an interior one costs nothing.  Row 2 and not
+                // the tile centre: reading acc[8] here makes the weight-resident instantiation spill (two reloads per tile;
+                // no time difference in an A/B, but the ISA lint then has something to report); rows 1 and 2 allocate without.  On an
+                // image under three rows high the value comes from the zero-filled halo: still a valid pivot, ~plain sums.
+                if (lx == (vx > 8 ? 8 : 0)) {
 #pragma unroll
                     for (int n = 0; n < NBW; ++n)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int cl = ch(kg, n, j);
-                            PV[cl] = mid_r ? acc[8][n][j] : acc[0][n][j];
+                            PV[cl] = acc[2][n][j];
                             S1[cl] = 0.f;
                             S2[cl] = 0.f;
                         }
@@ -1103,6 +1254,20 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             }
             n_run += (float)(vy * vx);
         }
+    }
+    if constexpr (BSUM) {
+        // one partial row per workgroup: [row][0][c] = sum g, [row][1][c] = rstd * sum g * (q - mean)
+        if (lx == 0) {
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = ch(kg, n, j);
+                    stats[((int64_t)tile_lane * 2 + 0) * Cout + co_blk + cl] = wg_sum[0][cl];
+                    stats[((int64_t)tile_lane * 2 + 1) * Cout + co_blk + cl] = wg_sum[1][cl] * bs_tab[3 * BN + cl];
+                }
+        }
+        return;
     }
     if (stats) {
         // row = tile lane of this workgroup; rows nlanes .. ntile-1 of the (per-tile sized) buffer get a zero pixel
@@ -1554,14 +1719,33 @@ static bool uh_no_wres() {
     return off;
 }
 
+// Which bf16 instantiation of conv3x3_fwd_mfma_v2 a plain call takes and how many tile lanes (= workgroups per channel slab =
+// statistics / partial rows written) it is launched with.  Mirrors the branches of conv3x3_fwd_dispatch below.
+struct FwdSel { int nbw; bool wres; int slabs; int gx; };
+static FwdSel fwd_select(int ntile, int Cin, int Cout, bool bf16_plain) {
+    auto lanes_for = [&](int per_cu, int slabs) {
+        int gx = (per_cu * 256 + slabs - 1) / slabs;
+        gx = (gx + 7) & ~7;
+        if (gx > ntile) gx = ntile;
+        return gx;
+    };
+    FwdSel r;
+    if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) { r.nbw = 2; r.wres = false; r.slabs = Cout / 128; r.gx = lanes_for(2, r.slabs); }
+    else if (bf16_plain && Cin == 64 && !uh_no_wres()) { r.nbw = 1; r.wres = true; r.slabs = Cout / 64; r.gx = lanes_for(2, r.slabs); }
+    else { r.nbw = 1; r.wres = false; r.slabs = Cout / 64; r.gx = lanes_for(3, r.slabs); }
+    return r;
+}
+
 template <typename T>
 static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C1, int ld1, const T* w, T* y, int ldy,
                                 int Cout, float* stats, int B, int H, int W, hipStream_t st, const float* ep_scale,
                                 const float* ep_shift, bool* ep_done, bool split = false, int C0v = -1, int C1v = -1,
                                 int Coutv = -1, bool wfrag = false, const float* pre_scale = nullptr,
-                                const float* pre_shift = nullptr) {
+                                const float* pre_shift = nullptr, const T* bs_y = nullptr, int bs_ld = 0,
+                                const float* bs_coef = nullptr) {
     const bool narrow = C0v >= 0;          // narrow tensors: only the LDS-DMA MFMA kernel implements the channel masks
     const bool pre = pre_scale != nullptr; // BatchNorm + ReLU of the producer applied to source 0 by this kernel's loader
+    const bool bsum = bs_y != nullptr;     // backward-data + the BatchNorm-backward sums of the tensor it differentiates (stats = the partial rows)
     if (!narrow) { C0v = C0; C1v = C1; Coutv = Cout; }
     // ep_scale/ep_shift (inference): kernels that apply them in their epilogue set *ep_done; for the others the caller
     // runs the separate scale/shift/ReLU pass
@@ -1618,6 +1802,34 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                     return UH_EINVAL;
                 }
             }
+            if (bsum) {
+                if constexpr (ES == 2) {
+                    const int64_t bq = (int64_t)B * H * W * bs_ld * ES;
+                    if (split || narrow || C1 != 0 || !stats || !bs_coef || bs_ld != ldy || !uh_aligned16(bs_y) || bq >= (1ll << 31) - 4096) {
+                        uh_set_error("uh_conv3x3_dgrad_bnsum: needs a plain single-source bf16 call and a 16-byte aligned BatchNorm input below 2 GiB; ask uh_conv3x3_dgrad_bnsum_rows first");
+                        return UH_EINVAL;
+                    }
+                    const FwdSel sel = fwd_select(ntile, Cin, Cout, true);
+                    const int wf = wfrag ? 1 : 0, grid = sel.gx * sel.slabs;
+                    if (sel.nbw == 2)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, false, false, false, true>), dim3(grid), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, nullptr, nullptr, C0v, C1v, Coutv, wf,
+                                           nullptr, nullptr, bs_y, bs_ld, (unsigned)bq, bs_coef);
+                    else if (sel.wres)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, true, false, true>), dim3(grid), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, nullptr, nullptr, C0v, C1v, Coutv, wf,
+                                           nullptr, nullptr, bs_y, bs_ld, (unsigned)bq, bs_coef);
+                    else
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, false, false, true>), dim3(grid), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, nullptr, nullptr, C0v, C1v, Coutv, wf,
+                                           nullptr, nullptr, bs_y, bs_ld, (unsigned)bq, bs_coef);
+                    UH_CHECK_LAUNCH("conv3x3_fwd_mfma_v2 (backward-data + BatchNorm sums)");
+                    return UH_OK;
+                } else {
+                    uh_set_error("uh_conv3x3_dgrad_bnsum: bf16 only; ask uh_conv3x3_dgrad_bnsum_rows first");
+                    return UH_EINVAL;
+                }
+            }
             if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
                 if (split) {
@@ -1648,6 +1860,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             return UH_OK;
         }
         if (pre) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs the LDS-DMA MFMA kernel (tensors below 2 GiB); ask uh_conv3x3_pre_ok first"); return UH_EINVAL; }
+        if (bsum) { uh_set_error("uh_conv3x3_dgrad_bnsum: needs the LDS-DMA MFMA kernel (tensors below 2 GiB); ask uh_conv3x3_dgrad_bnsum_rows first"); return UH_EINVAL; }
         if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but this call cannot take the LDS-DMA MFMA kernel (a tensor of 2 GiB or more); ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
         if (split) { uh_set_error("conv3x3_fwd: bf16x3 is implemented for tensors below 2 GiB only"); return UH_EINVAL; }
         if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors are implemented for tensors below 2 GiB only"); return UH_EINVAL; }
@@ -1662,6 +1875,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
         return UH_OK;
     }
     if (pre) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs an MFMA-aligned shape; ask uh_conv3x3_pre_ok first"); return UH_EINVAL; }
+    if (bsum) { uh_set_error("uh_conv3x3_dgrad_bnsum: needs an MFMA-aligned shape; ask uh_conv3x3_dgrad_bnsum_rows first"); return UH_EINVAL; }
     if (wfrag) { uh_set_error("conv3x3_fwd: the filter is packed fragment-major (UH_WFRAG) but the shape / alignment is outside the MFMA path; ask uh_conv3x3_wfrag_ok first"); return UH_EINVAL; }
     if (split) { uh_set_error("conv3x3_fwd: bf16x3 needs an MFMA-aligned shape (Cin %% 16 == 0, Cout %% 64 == 0, 16-byte strides)"); return UH_EINVAL; }
     if (narrow) { uh_set_error("conv3x3_fwd: narrow tensors need padded counts that are MFMA-aligned and 16-byte strides"); return UH_EINVAL; }
@@ -1766,6 +1980,39 @@ extern "C" int uh_conv3x3_fwd_pre(const void* x0, int C0, int ld0, const float* 
     return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, nullptr, 0, 0, (const bf16_t*)w, (bf16_t*)y, ldy, Cout,
                                         stat_partials, B, H, W, (hipStream_t)stream, nullptr, nullptr, &done, false, -1, -1, -1,
                                         wfrag, pre_scale, pre_shift);
+}
+
+// Backward-data of the second conv of a DoubleConv together with the first half of the BatchNorm backward of the layer in
+// front of it (see BSUM above).  dy [B,H,W,Cdy] -> dx [B,H,W,Cdx] with the backward-data filter pack; q = the raw output of the
+// first conv (what BatchNorm normalised), coef = its [scale | shift | mean | rstd] (Cdx floats each).  partials receives
+// uh_conv3x3_dgrad_bnsum_rows() rows of [2][Cdx]: feed them to uh_bn_relu_bwd_apply / uh_bn_bwd_finalize as (partials, nblk = rows)
+// in place of uh_bn_relu_bwd_reduce's.  rows == 0: the shape is outside the fused path, run the two kernels separately.
+extern "C" int uh_conv3x3_dgrad_bnsum_rows(int B, int H, int W, int Cdy, int Cdx, int lddy, int lddx, int ldq, int dt) {
+    if (dt != UH_BF16) return 0;
+    if (!uh_conv3x3_wfrag_ok(B, H, W, Cdy, 0, Cdx, lddy, 0, lddx, dt)) return 0;
+    if (ldq != lddx) return 0;                 // q is addressed with the offsets of the tensor being written
+    const int ntile = B * ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
+    return fwd_select(ntile, Cdy, Cdx, true).gx;
+}
+
+extern "C" int uh_conv3x3_dgrad_bnsum(const void* dy, int Cdy, int lddy, const void* w_dgrad, void* dx, int lddx, int Cdx,
+                                      const void* q, int ldq, const float* coef, float* partials, int B, int H, int W, int dt,
+                                      uh_stream stream) {
+    UH_REQUIRE(dy && w_dgrad && dx && q && coef && partials, "uh_conv3x3_dgrad_bnsum: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && Cdy > 0 && Cdx > 0, "uh_conv3x3_dgrad_bnsum: bad shape");
+    UH_REQUIRE(lddy >= Cdy && lddx >= Cdx && ldq >= Cdx, "uh_conv3x3_dgrad_bnsum: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_dgrad_bnsum: pixel count overflows int32");
+    const bool wfrag = (dt & UH_WFRAG) != 0;
+    dt &= ~UH_WFRAG;
+    UH_REQUIRE(dt == UH_BF16, "uh_conv3x3_dgrad_bnsum: bf16 only (dtype %d)", dt);
+    UH_REQUIRE(uh_aligned16(dy) && uh_aligned16(w_dgrad) && uh_aligned16(dx) && uh_aligned16(q) && uh_aligned16(coef),
+               "uh_conv3x3_dgrad_bnsum: pointers must be 16-byte aligned");
+    UH_REQUIRE(uh_conv3x3_dgrad_bnsum_rows(B, H, W, Cdy, Cdx, lddy, lddx, ldq, dt) > 0,
+               "uh_conv3x3_dgrad_bnsum: shape outside the fused path (uh_conv3x3_dgrad_bnsum_rows)");
+    bool done;
+    return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)dy, Cdy, lddy, nullptr, 0, 0, (const bf16_t*)w_dgrad, (bf16_t*)dx, lddx, Cdx,
+                                        partials, B, H, W, (hipStream_t)stream, nullptr, nullptr, &done, false, -1, -1, -1, wfrag,
+                                        nullptr, nullptr, (const bf16_t*)q, ldq, coef);
 }
 
 // Inference forward: z = max(conv(x, w) * scale + shift, 0) with the eval-mode BatchNorm coefficients of
@@ -2161,7 +2408,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 
     // per-thread DMA geometry that does not depend on the tile: halo coordinates of each 16-byte unit and its byte
     // offset relative to the tile's top-left halo pixel (tile-dependent part is one scalar base + 4 range checks)
-    int xg[XR], xo[XR], dg[DR], dof[DR];
+    int xg[XR], xo[XR];
 #pragma unroll
     for (int k = 0; k < XR; ++k) {
         const int p = tid + k * NT;
@@ -2175,13 +2422,18 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     // of a transposed read hit 4 distinct bank groups (128-byte pitch: bit 1 of the column flips the two groups; 256-byte
     // pitch: the two low column bits permute the four groups)
     auto dswz = [&](int col) -> int { return NWR == 2 ? (((col >> 1) & 1) << 2) : ((col & 3) << 2); };     // in 16-byte units
-#pragma unroll
-    for (int k = 0; k < DR; ++k) {
-        const int p = tid + k * NT;
-        const int q = p / DU, u = (p % DU) ^ dswz(q & 15);
-        dg[k] = (u * 8 < dleft) ? (((q >> 4) << 8) | (q & 15)) : -1;
-        dof[k] = ((q >> 4) * W + (q & 15)) * lddy * 2 + u * 16;
+    // A DMA round covers NT / DU = 32 pixels = two whole tile rows, so a thread's DR dy pieces sit in one column, 2 rows apart:
+    // piece k = piece 0 + k * (a wave-uniform stride).  One (coordinate, offset) pair per thread instead of DR of them -- the
+    // NWR = 2 instantiation spilled one of them and reloaded it, behind a vmcnt(0), in the middle of every tile's DMA issue
+    // (an A/B of the two builds shows no time difference: the reload hid behind the other resident workgroup's MFMAs).
+    static_assert(NT / DU == 2 * TILE, "dy DMA rounds are two tile rows apart");
+    int dg0, dof0;
+    {
+        const int q = tid / DU, u = (tid % DU) ^ dswz(q & 15);
+        dg0 = (u * 8 < dleft) ? (((q >> 4) << 8) | (q & 15)) : -1;
+        dof0 = ((q >> 4) * W + (q & 15)) * lddy * 2 + u * 16;
     }
+    const int dof_round = 2 * W * lddy * 2;       // bytes between rounds
     auto issue = [&](int tile, int bufi) {
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
@@ -2205,12 +2457,12 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         }
 #pragma unroll
         for (int k = 0; k < DR; ++k) {
-            bool ok = dg[k] >= 0;
+            bool ok = dg0 >= 0;
             if (!inside) {
-                const int gy = y0 + (dg[k] >> 8), gx = x0p + (dg[k] & 255);
+                const int gy = y0 + 2 * k + (dg0 >> 8), gx = x0p + (dg0 & 255);
                 ok = ok && gy < H && gx < W;
             }
-            uh_dma16(rsd, db + k * RB, ok ? (unsigned)(dbase + dof[k]) : OOB_OFFSET, 0);
+            uh_dma16(rsd, db + k * RB, ok ? (unsigned)(dbase + k * dof_round + dof0) : OOB_OFFSET, 0);
         }
     };
 

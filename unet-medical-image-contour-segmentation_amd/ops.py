@@ -16,7 +16,8 @@ from ._lib import LIB, UH_BF16, UH_F32, UH_F32X3, UH_WFRAG, UH_WFRAG_D
 
 BN_EPS_DEFAULT = 1e-5
 
-# optional per-launch timing (bench.py): (kernel family, algorithmic FLOPs, start event, end event)
+# optional per-launch timing (bench.py): (kernel family, algorithmic FLOPs, start event, end event, tag) with
+# tag = (direction, B, H, W, input channels, output channels) on the 3x3 conv launches, None elsewhere
 PROFILE_ON = False
 PROFILE = []
 
@@ -30,8 +31,8 @@ def _variant(Cin_split, Cout, esize):
 
 
 class _Timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, tag=None):
+        self.name, self.flops, self.tag = name, flops, tag
 
     def __enter__(self):
         if PROFILE_ON:
@@ -43,7 +44,7 @@ class _Timed:
     def __exit__(self, *a):
         if PROFILE_ON:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.tag))
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -322,7 +323,7 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
         nslab = LIB.query("uh_conv3x3_stat_slabs", B, H, W, C0 + C1, Cout, dt)
         stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=x0.device)
     name = "conv3x3_fwd_" + _variant((C0, C1), Cout, x0.element_size())
-    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1)):
+    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1), ("fwd" if want_stats else "dgrad", B, H, W, C0 + C1, Cout)):
         LIB.call("uh_conv3x3_fwd", x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1, 0 if x1 is None else pixel_ld(x1),
                  w_packed.data_ptr(), y.data_ptr(), Cout, Cout, _p(stats), B, H, W, dt | (UH_WFRAG if wfrag else 0), _stream())
     return y, stats, nslab
@@ -340,7 +341,7 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     name = "conv3x3_wgrad_" + ("mfma" if (C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0) else
                                 ("stem" if C0 + C1 <= 4 else "generic"))
-    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1)):
+    with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1), ("wgrad", B, H, W, C0 + C1, Cout)):
         LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
                  0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
 
@@ -496,6 +497,26 @@ def pre_fuse_ok(x0: torch.Tensor, mid: int, Cout: int) -> bool:
     return bool(LIB.query("uh_conv3x3_pre_ok", B, H, W, mid, Cout, mid, Cout, UH_BF16))
 
 
+# ---- BatchNorm-backward sums formed by the NEXT conv's backward-data.  Inside a DoubleConv the
+# gradient of the activation between the two convs is produced by the second conv's backward-data and read back at once by
+# uh_bn_relu_bwd_reduce (that tensor + the first conv's raw output).  uh_conv3x3_dgrad_bnsum forms the two per-channel sums in the
+# conv epilogue instead -- accumulators still in registers, one read of the raw output -- and the reduce pass is not launched
+# (8 of the 12 plain BatchNorm layers of the bilinear UNet).  UH_FUSE_BNSUM=0 turns it off.
+FUSE_BNSUM = os.environ.get("UH_FUSE_BNSUM", "1") != "0"
+
+
+class BnSumLink:
+    """What ties the two ConvBnReluFn nodes of a DoubleConv together for that fusion: the first layer publishes its raw conv
+    output and BatchNorm coefficients in forward; the second layer's backward leaves the partial sums (and the gradient tensor
+    they belong to); the first layer's backward uses them if the gradient it receives IS that tensor (autograd hands over the
+    same storage when the activation had no other consumer), else it runs the reduce pass as before."""
+    __slots__ = ("y", "coef", "dz", "partials", "rows")
+
+    def __init__(self):
+        self.y = self.coef = self.dz = self.partials = None
+        self.rows = 0
+
+
 class ConvBnReluFn(Function):
     """(nn.Conv2d(3x3, pad 1, no bias) -> nn.BatchNorm2d -> nn.ReLU) of unet_parts.py:15-17 / 18-20 as
     one autograd node.  Inputs: x0 (+ optional x1 = second half of the channel concat of
@@ -508,8 +529,11 @@ class ConvBnReluFn(Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
                 training: bool, momentum: float, eps: float, tail: int = 0, head_w=None, head_b=None,
-                defer: bool = False, pre_coef=None):
-        """`defer` (training, no tail): the BatchNorm + ReLU of THIS layer is left to its consumer -- returns (y, coef): the raw
+                defer: bool = False, pre_coef=None, bnsum_pub: Optional[BnSumLink] = None,
+                bnsum_use: Optional[BnSumLink] = None):
+        """`bnsum_pub` / `bnsum_use` (BnSumLink): this layer is the first / the second conv of a DoubleConv whose
+        BatchNorm-backward sums may be formed by the second conv's backward-data.
+        `defer` (training, no tail): the BatchNorm + ReLU of THIS layer is left to its consumer -- returns (y, coef): the raw
         conv output standing in for the activation (its gradient is the activation's gradient) and the [scale | shift | mean
         | rstd] coefficients.  `pre_coef`: x0 is such a raw output; its BatchNorm + ReLU is applied by this layer's conv
         loaders (forward and backward-weights), the activation is never stored."""
@@ -575,6 +599,13 @@ class ConvBnReluFn(Function):
         ctx.sync_bn = SYNC_BN if n_total != n else None
         ctx.tail = tail
         ctx.pre = pre_coef is not None
+        ctx.bnsum_pub = ctx.bnsum_use = None
+        if FUSE_BNSUM and x0.dtype == torch.bfloat16 and cdt == UH_BF16:
+            if bnsum_pub is not None and tail == TAIL_NONE and not defer:
+                bnsum_pub.y, bnsum_pub.coef = y, coef
+                ctx.bnsum_pub = bnsum_pub
+            if bnsum_use is not None and bnsum_use.y is not None and x1 is None and pre_coef is None:
+                ctx.bnsum_use = bnsum_use
         if pre_coef is not None:
             x1 = pre_coef                      # rides in the saved-tensor slot of the (absent) second source
         if defer:
@@ -670,12 +701,23 @@ class ConvBnReluFn(Function):
         else:
             dz = grads[0]
             if dz is None:          # pool tail whose outputs were both unused
-                return (None,) * 16
+                return (None,) * 18
             dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
+            link = ctx.bnsum_pub
+            if link is not None:
+                # the sums came with the gradient (uh_conv3x3_dgrad_bnsum in the consumer's backward) -- if this IS that gradient
+                if link.partials is not None and link.dz is not None and dz.data_ptr() == link.dz.data_ptr() and \
+                        dz.shape == link.dz.shape and dz.stride() == link.dz.stride():
+                    partials, nblk = link.partials, link.rows
+                else:
+                    link = None
+                ctx.bnsum_pub.partials = ctx.bnsum_pub.dz = ctx.bnsum_pub.y = ctx.bnsum_pub.coef = None
+            fused_sums = link is not None
 
             def reduce():
-                LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), *bn_args, partials.data_ptr(), n, Cout, dt,
-                         _stream())
+                if not fused_sums:
+                    LIB.call("uh_bn_relu_bwd_reduce", dz.data_ptr(), pixel_ld(dz), *bn_args, partials.data_ptr(), n, Cout, dt,
+                             _stream())
 
             def apply(part_ptr, nb, dg_ptr, db_ptr, n_total):
                 LIB.call("uh_bn_relu_bwd_apply", dz.data_ptr(), pixel_ld(dz), *bn_args, part_ptr, nb, dg_ptr, db_ptr,
@@ -701,7 +743,23 @@ class ConvBnReluFn(Function):
         # layer's own MFMA-bound backward-data.
         dx0 = dx1 = None
         if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt, ctx.frag_d)
+            use = ctx.bnsum_use
+            rows = 0
+            if use is not None and use.y is not None and use.y.shape == (B, H, W, Cin) and use.y.is_contiguous():
+                rows = LIB.query("uh_conv3x3_dgrad_bnsum_rows", B, H, W, Cout, Cin, Cout, Cin, Cin, ctx.cdt)
+            if rows > 0:
+                # backward-data + the BatchNorm-backward sums of the layer in front (its reduce pass is not launched)
+                dx = torch.empty((B, H, W, Cin), dtype=dy.dtype, device=dev)
+                bsum = torch.empty(rows * 2 * Cin, dtype=torch.float32, device=dev)
+                # (a kernel family of its own in bench.py's profile: the same MFMA work as plain backward-data plus a read of
+                # `use.y` and the sums -- its time is not comparable with the plain launches')
+                with _Timed("conv3x3_dgrad_bnsum_mfma", 2.0 * B * H * W * Cin * 9 * Cout, ("dgrad", B, H, W, Cout, Cin)):
+                    LIB.call("uh_conv3x3_dgrad_bnsum", dy.data_ptr(), Cout, Cout, wd.data_ptr(), dx.data_ptr(), Cin, Cin,
+                             use.y.data_ptr(), Cin, use.coef.data_ptr(), bsum.data_ptr(), B, H, W,
+                             ctx.cdt | (UH_WFRAG if ctx.frag_d else 0), _stream())
+                use.partials, use.rows, use.dz = bsum, rows, dx
+            else:
+                dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt, ctx.frag_d)
             dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
             dx1 = dx[..., C0:] if (x1 is not None and ctx.needs_input_grad[1]) else None
         # weight gradient: straight into the parameter's layout when that IS KRSC (channels_last weights)
@@ -748,7 +806,7 @@ class ConvBnReluFn(Function):
             dgamma = None
         if not ctx.needs_input_grad[4]:
             dbeta = None
-        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None
+        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None, None, None
 
 
 # ----------------------------------------------------------------------------- the stem, output recomputed

@@ -46,7 +46,7 @@ def _finish_tail(z, tail):
 
 
 def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, keep_padded: bool = False,
-                  x0_channels: int = None, tail=None, defer: bool = False, pre_coef=None):
+                  x0_channels: int = None, tail=None, defer: bool = False, pre_coef=None, bnsum_pub=None, bnsum_use=None):
     """One (conv3x3 -> BatchNorm -> ReLU) layer, plus its consumer `tail` (see _finish_tail) -- fused into the BatchNorm
     kernels where csrc/bn_fused.hip covers the shape (training, 64-aligned layers), separate kernels otherwise.
     Layers whose channel counts are not multiples of 64 (the small-width UNet_S / UNet_T of unet_model.py:52-126) are computed as the next larger 64-aligned layer with zero filters / unit
@@ -75,11 +75,12 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
                 bn.eps)
         if defer:      # (the caller has checked ops.pre_fuse_ok: this layer's BatchNorm + ReLU is applied by its consumer)
             return ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, True, None)
+        link = (bnsum_pub, bnsum_use) if training else (None, None)      # (ops.BnSumLink: see DoubleConv.nhwc)
         if training and tail == "pool" and ops.pool_tail_ok(x0, Cout):
-            return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None, False, pre_coef)
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None, False, pre_coef, *link)
         if training and isinstance(tail, OutConv) and ops.head_tail_ok(x0, Cout, tail.conv.weight):
-            return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias, False, pre_coef)
-        return _finish_tail(ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, False, pre_coef), tail)
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias, False, pre_coef, *link)
+        return _finish_tail(ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, False, pre_coef, *link), tail)
     if defer or pre_coef is not None:
         raise RuntimeError("a deferred BatchNorm+ReLU needs 64-aligned layers (ops.pre_fuse_ok)")
     if ops.NARROW_IO and x0_channels is None:
@@ -141,9 +142,12 @@ class DoubleConv(nn.Module):
             # BatchNorm + ReLU to its raw output on the way to the MFMAs
             y1, coef1 = _conv_bn_relu(x0, x1, seq[0], seq[1], True, defer=True)
             return _conv_bn_relu(y1, None, seq[3], seq[4], True, tail=tail, pre_coef=coef1)
-        h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training, keep_padded=True)
+        # the first layer's BatchNorm-backward sums are formed by the second conv's backward-data where the shapes allow
+        # (ops.BnSumLink; bf16 training, 64-aligned layers -- the link stays unused everywhere else)
+        link = ops.BnSumLink() if (self.training and ops.FUSE_BNSUM) else None
+        h = _conv_bn_relu(x0, x1, seq[0], seq[1], self.training, keep_padded=True, bnsum_pub=link)
         return _conv_bn_relu(h, None, seq[3], seq[4], self.training, x0_channels=mid if h.shape[-1] != mid else None,
-                             tail=tail)
+                             tail=tail, bnsum_use=link)
 
     def forward(self, x):
         return ops.to_nchw(self.nhwc(ops.to_nhwc(x, ops.compute_dtype(x.dtype if x.dtype == torch.bfloat16 else torch.float32))))
