@@ -22,9 +22,8 @@ __device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, dou
     a.n = n;
 }
 
-// Rows with a zero pixel count are skipped (producers that use fewer rows than
-// the buffer holds zero the counts of the rest); the number of leading rows to walk is found first.  Chan merge in
-// double, then the affine coefficients, the running statistics and num_batches_tracked.
+// Rows with a zero pixel count are skipped (producers that use fewer rows than the buffer holds zero the counts of the rest).
+// Two-pass merge in double (mean, then M2 about it), then the affine coefficients, the running statistics and num_batches_tracked.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int ldc, int C, double n,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
@@ -38,19 +37,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 16 + cl;
     const float* cnt = stats + (int64_t)nslab * 2 * ldc;      // ldc: channels per stat row (>= C)
-    if (threadIdx.x == 0) last_row = -1;
-    __syncthreads();
-    int last = -1;
-    for (int s = threadIdx.x; s < nslab; s += 1024)
-        if (cnt[s] > 0.f) last = s;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    if ((threadIdx.x & 63) == 0 && last >= 0) atomicMax(&last_row, last);
-    __syncthreads();
-    const int R = last_row + 1;
-    // Two passes over the (L2-resident) rows instead of a chain of Chan merges (each merge costs a double division):
-    //   mean = sum_i n_i*mean_i / N,   M2 = sum_i [ M2_i + n_i*(mean_i - mean)^2 ]
-    // cross-lane sums: the 4 row lanes of a wave by shuffles (lane bits 4,5), the 16 waves through LDS
+    // Every thread owns rows sl, sl + 64, ...  The rows were written by the previous kernel from all eight XCDs, so every
+    // load here is an HBM / MALL round trip, and the kernel is nothing but dependent round trips.  The MFMA conv kernels write at
+    // most 768 live rows (one per workgroup) into a buffer sized for one row per TILE, so the first FAST_ROWS rows are fetched
+    // unconditionally -- 12 per thread, clamped index, no branch in between, the count tests applied to the VALUES -- in the SAME
+    // round trip in which the counts of all the rows behind them are scanned.  Only a producer with more live rows than that
+    // (the per-tile statistics of the generic kernels) takes the second trip: find the last live row, walk the rest in batches.
+    // Cross-lane sums: the 4 row lanes of a wave by shuffles (lane bits 4,5), the 16 waves through LDS.
     auto block_sum = [&](double v, int slot) -> double {
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
@@ -61,53 +54,90 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         for (int k = 0; k < 16; ++k) t += red[slot][k][cl];
         return t;
     };
-    // Every thread owns rows sl, sl + 64, ...  The rows were written by the previous kernel from all eight XCDs, so every
-    // load here is an HBM / MALL round trip: batches of 6 rows are fetched with no branch in between (clamped row index,
-    // the range / count tests are applied to the VALUES), pass 2 reuses the registers when one batch covered all rows --
-    // a load behind `if (count > 0)` made 2 x 12 dependent round trips per pass (21 us for a 64-channel 512x512 layer).
-    constexpr int MAXI = 6;
+    constexpr int MAXI = 12, FAST_ROWS = 64 * MAXI;
     const int cc = c < C ? c : C - 1;
-    const bool single = R <= 64 * MAXI;
-    double a = 0.0, cn = 0.0;
+    if (threadIdx.x == 0) last_row = -1;
     float nfr[MAXI], mvr[MAXI], m2r[MAXI];
-    for (int base = 0; base < R; base += 64 * MAXI) {
+    const int R0 = nslab < FAST_ROWS ? nslab : FAST_ROWS;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int f = sl + 64 * i;
+        const int fc = f < R0 ? f : R0 - 1;
+        nfr[i] = cnt[fc];
+        mvr[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
+        m2r[i] = stats[((int64_t)fc * 2 + 1) * ldc + cc];
+        if (f >= R0) nfr[i] = 0.f;
+    }
+    int last = -1;
+    for (int s0 = FAST_ROWS + threadIdx.x; s0 < nslab; s0 += 8 * 1024) {      // eight independent loads per trip (8 192 tiles: one trip)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = s0 + u * 1024;
+            v[u] = cnt[idx < nslab ? idx : nslab - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = s0 + u * 1024;
+            if (idx < nslab && v[u] > 0.f) last = idx;
+        }
+    }
+    __syncthreads();                                  // last_row initialised
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if ((threadIdx.x & 63) == 0 && last >= 0) atomicMax(&last_row, last);
+    __syncthreads();
+    const int R = last_row + 1;                       // 0: every live row is among the first FAST_ROWS
+    const bool single = R <= FAST_ROWS;
+    double a = 0.0, cn = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const double nf = (double)nfr[i];
+        const bool live = nfr[i] > 0.f;                // rows with a zero count may hold anything
+        a = live ? fma(nf, (double)mvr[i], a) : a;
+        cn = live ? cn + nf : cn;
+    }
+    for (int base = FAST_ROWS; base < R; base += FAST_ROWS) {
+        float nf2[MAXI], mv2[MAXI];
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int f = base + sl + 64 * i;
             const int fc = f < R ? f : R - 1;
-            nfr[i] = cnt[fc];
-            mvr[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
-            m2r[i] = stats[((int64_t)fc * 2 + 1) * ldc + cc];
-            if (f >= R) nfr[i] = 0.f;
+            nf2[i] = f < R ? cnt[fc] : 0.f;
+            mv2[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
         }
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
-            const double nf = (double)nfr[i];
-            const bool live = nfr[i] > 0.f;            // rows with a zero count may hold anything
-            a = live ? fma(nf, (double)mvr[i], a) : a;
-            cn = live ? cn + nf : cn;
+            const double nf = (double)nf2[i];
+            a = nf2[i] > 0.f ? fma(nf, (double)mv2[i], a) : a;
+            cn = nf2[i] > 0.f ? cn + nf : cn;
         }
     }
     const double A = block_sum(a, 0), N = block_sum(cn, 1);
     const double mean = N > 0.0 ? A / N : 0.0;
     double q = 0.0;
-    for (int base = 0; base < R; base += 64 * MAXI) {
-        if (!single) {
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {                   // the first FAST_ROWS rows: still in registers
+        const double nf = (double)nfr[i];
+        const double d = (double)mvr[i] - mean;
+        q = nfr[i] > 0.f ? q + ((double)m2r[i] + nf * d * d) : q;
+    }
+    if (!single) {
+        for (int base = FAST_ROWS; base < R; base += FAST_ROWS) {
 #pragma unroll
             for (int i = 0; i < MAXI; ++i) {
                 const int f = base + sl + 64 * i;
                 const int fc = f < R ? f : R - 1;
-                nfr[i] = cnt[fc];
+                nfr[i] = f < R ? cnt[fc] : 0.f;
                 mvr[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
                 m2r[i] = stats[((int64_t)fc * 2 + 1) * ldc + cc];
-                if (f >= R) nfr[i] = 0.f;
             }
-        }
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const double nf = (double)nfr[i];
-            const double d = (double)mvr[i] - mean;
-            q = nfr[i] > 0.f ? q + ((double)m2r[i] + nf * d * d) : q;
+            for (int i = 0; i < MAXI; ++i) {
+                const double nf = (double)nfr[i];
+                const double d = (double)mvr[i] - mean;
+                q = nfr[i] > 0.f ? q + ((double)m2r[i] + nf * d * d) : q;
+            }
         }
     }
     Moments m = {N, mean, block_sum(q, 2)};
