@@ -257,6 +257,14 @@ int uh_maxpool2_bwd(const void* x, int ldx, const void* dy, int lddy, const void
  * of y is zero filled. */
 int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B, int h, int w, int C,
                       int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
+/* The same with the BatchNorm + ReLU in front of it applied on the way in: x is the RAW output of the last conv below an Up block
+ * (unet_model.py:34-37), the activation max(x*scale + shift, 0) -- read by nothing but nn.Upsample (unet_parts.py:70,80) -- is
+ * rounded to the tensor dtype as uh_bn_relu_apply would store it and interpolated, never written.  Bit-identical to
+ * uh_bn_relu_apply + uh_upsample2x_fwd.  uh_bn_relu_upsample2x_ok: 1 when the shape takes the fused kernel (C a multiple of a
+ * 16-byte piece; pointers / strides 16-byte aligned are checked by the call). */
+int uh_bn_relu_upsample2x_ok(int B, int h, int w, int C, int Ho, int Wo, int dt);
+int uh_bn_relu_upsample2x_fwd(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,
+                              int B, int h, int w, int C, int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
 int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int B, int h, int w, int C,
                       int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream);
 

@@ -217,3 +217,49 @@ def test_unet_step_same_with_and_without_fused_tails(amp, bilinear, n_classes):
     tol = 2e-2 if amp else 2e-4
     for k in grads_u:
         assert _rel(grads_f[k], grads_u[k]) < tol, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,h,w,C,Ho,Wo", [(2, 32, 32, 512, 64, 64), (1, 33, 17, 64, 67, 35), (3, 5, 7, 128, 10, 14), (8, 64, 64, 256, 128, 128)])
+def test_up_tail_is_bit_identical_to_apply_then_upsample(dtype, B, h, w, C, Ho, Wo):
+    """uh_bn_relu_upsample2x_fwd (BatchNorm + ReLU + bilinear x2 + F.pad in one pass, the activation never stored) against
+    uh_bn_relu_apply followed by uh_upsample2x_fwd: the same roundings in the same order, so every bit must agree -- incl. the
+    zero border of an odd skip extent (unet_parts.py:85-88)."""
+    from unet_amd import ops
+    from unet_amd._lib import LIB, UH_BF16, UH_F32
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + h * 3 + C)
+    dt = UH_BF16 if dtype == torch.bfloat16 else UH_F32
+    y = torch.randn(B, h, w, C, generator=g).to(dev, dtype)
+    scale = (torch.rand(C, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(C, generator=g) * 0.3).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert LIB.query("uh_bn_relu_upsample2x_ok", B, h, w, C, Ho, Wo, dt)
+    pt, pl = ops._pad_geometry(h, w, Ho, Wo)
+    z = torch.empty_like(y)
+    LIB.call("uh_bn_relu_apply", y.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), C, B * h * w, C, dt, st)
+    ref = torch.full((B, Ho, Wo, C), float("nan"), dtype=dtype, device=dev)
+    LIB.call("uh_upsample2x_fwd", z.data_ptr(), C, ref.data_ptr(), C, B, h, w, C, Ho, Wo, pt, pl, dt, st)
+    got = torch.full_like(ref, float("nan"))
+    LIB.call("uh_bn_relu_upsample2x_fwd", y.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), got.data_ptr(), C, B, h, w, C, Ho, Wo,
+             pt, pl, dt, st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} elements differ"
+    # and the reference leg is what torch computes from the stored activation (guards the leg itself)
+    want = torch.nn.functional.interpolate(z.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    want = torch.nn.functional.pad(want, [pl, Wo - 2 * w - pl, pt, Ho - 2 * h - pt]).permute(0, 2, 3, 1)
+    assert float((ref.float() - want).abs().max()) <= (2 ** -7 if dtype == torch.bfloat16 else 1e-5) * max(1.0, float(want.abs().max()))
+
+
+def test_up_tail_refuses_what_it_cannot_do():
+    from unet_amd._lib import LIB, UH_BF16
+    assert not LIB.query("uh_bn_relu_upsample2x_ok", 2, 8, 8, 12, 16, 16, UH_BF16)       # channels not a multiple of a 16-byte piece
+    assert not LIB.query("uh_bn_relu_upsample2x_ok", 2, 8, 8, 64, 15, 16, UH_BF16)       # target smaller than the up-sampled image
+    dev = _dev()
+    y = torch.zeros(2, 8, 8, 12, dtype=torch.bfloat16, device=dev)
+    c = torch.zeros(12, device=dev)
+    out = torch.zeros(2, 16, 16, 12, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="uh_bn_relu_upsample2x_ok"):
+        LIB.call("uh_bn_relu_upsample2x_fwd", y.data_ptr(), 12, c.data_ptr(), c.data_ptr(), out.data_ptr(), 12, 2, 8, 8, 12, 16, 16, 0, 0,
+                 UH_BF16, torch.cuda.current_stream().cuda_stream)

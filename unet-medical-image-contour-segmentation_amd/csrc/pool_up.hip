@@ -173,10 +173,14 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 // coordinates are scalar, a thread = (output column, 16-byte channel group) loads the input rows those four output
 // rows touch (x 2 columns; at most 4), interpolates them horizontally once, and blends each output row from two of the three
 // horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
-template <typename T, int V>
+// PRE: x is the RAW output of a conv and the activation that is up-sampled, max(x * scale + shift, 0) rounded to T exactly as
+// uh_bn_relu_apply would have stored it, is formed on the way in (uh_bn_relu_upsample2x_fwd: that activation has no other reader).
+template <typename T, int V, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                                   int h, int w, int C, int Ho, int Wo, int pt, int pl,
-                                                                  float sy, float sx, int gshift) {
+                                                                  float sy, float sx, int gshift,
+                                                                  const float* __restrict__ pre_scale = nullptr,
+                                                                  const float* __restrict__ pre_shift = nullptr) {
     constexpr int R = 4;
     const int G = C / V;
     const int groups = (Ho + R - 1) / R;
@@ -203,6 +207,11 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
     float hr[NR][V];                                   // horizontally interpolated input rows base .. base+3
     if (col_in) {
         const UpCoord cx = up_coord(ux, sx, w);
+        float sc[PRE ? V : 1], sh[PRE ? V : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { sc[i] = pre_scale[c + i]; sh[i] = pre_shift[c + i]; }
+        }
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int iy = min(base + j, h - 1);
@@ -210,8 +219,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
             float v0[V], v1[V];
             uh_load<T, V>(rp + (int64_t)cx.i0 * ldx, v0);
             uh_load<T, V>(rp + (int64_t)cx.i1 * ldx, v1);
+            if constexpr (PRE) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) hr[j][i] = cx.l0 * v0[i] + cx.l1 * v1[i];
+                for (int i = 0; i < V; ++i) {
+                    v0[i] = uh_round_as<T>(uh_relu(fmaf(v0[i], sc[i], sh[i])));
+                    v1[i] = uh_round_as<T>(uh_relu(fmaf(v1[i], sc[i], sh[i])));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) hr[j][i] = fmaf(cx.l0, v0[i], __fmul_rn(cx.l1, v1[i]));     // spelled out: both instantiations round alike
         }
     }
 #pragma unroll
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
             pick(a, ra);
             pick(bb, rb);
 #pragma unroll
-            for (int i = 0; i < V; ++i) o[i] = l0 * ra[i] + l1 * rb[i];
+            for (int i = 0; i < V; ++i) o[i] = fmaf(l0, ra[i], __fmul_rn(l1, rb[i]));
         }
         uh_store<T, V>(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c, o);
     }
@@ -438,6 +454,38 @@ extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B
                                (T*)y, ldy, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
     });
     UH_CHECK_LAUNCH("upsample2x_fwd_kernel");
+    return UH_OK;
+}
+
+// BatchNorm + ReLU + bilinear x2 (+ F.pad) in one pass: z = max(x * scale + shift, 0) of the last DoubleConv layer below an Up
+// block is read by nothing but the Up block's nn.Upsample (unet_model.py:34-37 / unet_parts.py:70,80), so it is never stored: the
+// raw conv output goes in, the up-sampled activation comes out.  Bit-identical to uh_bn_relu_apply followed by uh_upsample2x_fwd.
+extern "C" int uh_bn_relu_upsample2x_ok(int B, int h, int w, int C, int Ho, int Wo, int dt) {
+    if (dt != UH_F32 && dt != UH_BF16) return 0;
+    const int vec = dt == UH_BF16 ? 8 : 4;
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || C % vec != 0) return 0;
+    if (Ho < 2 * h || Wo < 2 * w) return 0;
+    return ((int64_t)Wo * (C / vec) < (1 << 23) && (int64_t)B * Ho < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int uh_bn_relu_upsample2x_fwd(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy, int B,
+                                         int h, int w, int C, int Ho, int Wo, int pad_top, int pad_left, int dt, uh_stream stream) {
+    UH_REQUIRE(x && y && scale && shift && ldx >= C && ldy >= C, "uh_bn_relu_upsample2x_fwd: bad args");
+    UH_REQUIRE(uh_bn_relu_upsample2x_ok(B, h, w, C, Ho, Wo, dt), "uh_bn_relu_upsample2x_fwd: shape outside the fused path (uh_bn_relu_upsample2x_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    float sy = up_scale(h), sx = up_scale(w);
+    UH_DISPATCH_DT(dt, T, {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        UH_REQUIRE((uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C)), "uh_bn_relu_upsample2x_fwd: tensors must be 16-byte aligned with 16-byte pixel strides");
+        const int G = C / VEC;
+        int gshift = -1;
+        for (int k = 0; k < 24; ++k)
+            if ((1 << k) == G) gshift = k;
+        const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
+        hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC, true>), dim3((unsigned)(B * ((Ho + 3) / 4)), gy), dim3(256), 0, st, (const T*)x,
+                           ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift, scale, shift);
+    });
+    UH_CHECK_LAUNCH("upsample2x_fwd_rows_kernel (BatchNorm + ReLU input)");
     return UH_OK;
 }
 

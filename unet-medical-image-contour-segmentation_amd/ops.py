@@ -464,12 +464,21 @@ def _sync_bn_forward(coef, m2, n_local, Cout, g32, b32, running_mean, running_va
 # activation is skip connection + max-pool input (every encoder level), TAIL_HEAD where it only feeds the 1x1 OutConv.
 # False: the separate kernels (A/B measurements; the tests compare both).
 FUSE_TAILS = True
-TAIL_NONE, TAIL_POOL, TAIL_HEAD = 0, 1, 2
+TAIL_NONE, TAIL_POOL, TAIL_HEAD, TAIL_UP = 0, 1, 2, 3
 
 
 def pool_tail_ok(x0: torch.Tensor, Cout: int) -> bool:
     B, H, W, _ = x0.shape
     return bool(FUSE_TAILS and LIB.query("uh_bn_relu_pool_ok", B, H, W, Cout, _dt(x0)))
+
+
+FUSE_UP_TAIL = os.environ.get("UH_FUSE_UP_TAIL", "1") != "0"      # (A/B switch of the up-sampling tail alone)
+
+
+def up_tail_ok(x0: torch.Tensor, Cout: int, Ho: int, Wo: int) -> bool:
+    """May (BatchNorm -> ReLU -> nn.Upsample(2, bilinear) -> F.pad to Ho x Wo) run as one kernel behind this layer's conv?"""
+    B, H, W, _ = x0.shape
+    return bool(FUSE_TAILS and FUSE_UP_TAIL and LIB.query("uh_bn_relu_upsample2x_ok", B, H, W, Cout, Ho, Wo, _dt(x0)))
 
 
 def head_tail_ok(x0: torch.Tensor, Cout: int, head_weight: torch.Tensor) -> bool:
@@ -524,13 +533,14 @@ class ConvBnReluFn(Function):
 
     `tail` (training only): TAIL_POOL -> returns (z, maxpool2(z)) (unet_parts.py:32 on top), the backward takes
     (dskip, dpool) and never materialises their sum; TAIL_HEAD -> returns the fp32 logits of the 1x1 OutConv
-    (head_w [ncls,Cout,1,1], head_b; unet_parts.py:103) and z is never written."""
+    (head_w [ncls,Cout,1,1], head_b; unet_parts.py:103) and z is never written; TAIL_UP (up_size = (Ho, Wo)) -> returns the
+    bilinear x2 up-sampling of z zero-padded to Ho x Wo (unet_parts.py:70,80,85-88: z's only reader) and z is never written."""
 
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
                 training: bool, momentum: float, eps: float, tail: int = 0, head_w=None, head_b=None,
                 defer: bool = False, pre_coef=None, bnsum_pub: Optional[BnSumLink] = None,
-                bnsum_use: Optional[BnSumLink] = None):
+                bnsum_use: Optional[BnSumLink] = None, up_size=None):
         """`bnsum_pub` / `bnsum_use` (BnSumLink): this layer is the first / the second conv of a DoubleConv whose
         BatchNorm-backward sums may be formed by the second conv's backward-data.
         `defer` (training, no tail): the BatchNorm + ReLU of THIS layer is left to its consumer -- returns (y, coef): the raw
@@ -622,6 +632,15 @@ class ConvBnReluFn(Function):
             ctx.save_for_backward(x0, x1, y, coef, wd, weight, hw2)
             ctx.head_params = (head_w, head_b)
             return logits
+        if tail == TAIL_UP:
+            Ho, Wo = up_size
+            pt, pl = _pad_geometry(H, W, Ho, Wo)
+            u = torch.empty((B, Ho, Wo, Cout), dtype=y.dtype, device=dev)
+            LIB.call("uh_bn_relu_upsample2x_fwd", y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), u.data_ptr(), Cout,
+                     B, H, W, Cout, Ho, Wo, pt, pl, _dt(y), _stream())
+            ctx.up = (Ho, Wo, pt, pl)
+            ctx.save_for_backward(x0, x1, y, coef, wd, weight)
+            return u
         z = torch.empty_like(y)
         if tail == TAIL_POOL:
             pooled = torch.empty((B, H // 2, W // 2, Cout), dtype=y.dtype, device=dev)
@@ -701,8 +720,13 @@ class ConvBnReluFn(Function):
         else:
             dz = grads[0]
             if dz is None:          # pool tail whose outputs were both unused
-                return (None,) * 18
+                return (None,) * 19
             dz = dense_nhwc(dz if dz.dtype == y.dtype else dz.to(y.dtype))
+            if tail == TAIL_UP:     # the gradient arrives for the up-sampled tensor: transpose of the interpolation first
+                Ho, Wo, pt, pl = ctx.up
+                du, dz = dz, torch.empty((B, H, W, Cout), dtype=y.dtype, device=dev)
+                LIB.call("uh_upsample2x_bwd", du.data_ptr(), pixel_ld(du), dz.data_ptr(), Cout, B, H, W, Cout, Ho, Wo, pt, pl,
+                         dt, _stream())
             link = ctx.bnsum_pub
             if link is not None:
                 # the sums came with the gradient (uh_conv3x3_dgrad_bnsum in the consumer's backward) -- if this IS that gradient
@@ -806,7 +830,7 @@ class ConvBnReluFn(Function):
             dgamma = None
         if not ctx.needs_input_grad[4]:
             dbeta = None
-        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None, None, None
+        return dx0, dx1, dweight, dgamma, dbeta, None, None, None, None, None, None, None, dhead[0], dhead[1], None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- the stem, output recomputed

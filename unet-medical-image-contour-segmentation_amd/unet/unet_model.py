@@ -53,10 +53,21 @@ class UNetDepth(nn.Module):
                 skip, pooled = block.nhwc(pooled, tail="pool")
                 skips.append(skip)
             else:
-                h = block.nhwc(pooled)
+                h = block.nhwc(pooled, tail=self._up_tail(1, skips))
         for j in range(1, self.depth + 1):
-            h = getattr(self, f"up{j}").nhwc(h, skips[self.depth - j], tail=self.outc if j == self.depth else None)
+            up = getattr(self, f"up{j}")
+            tail = self.outc if j == self.depth else self._up_tail(j + 1, skips)
+            h = up.nhwc(h, skips[self.depth - j], tail=tail, upsampled=up.bilinear)
         return h
+
+    def _up_tail(self, j: int, skips):
+        """What consumes the tensor handed to Up block j: with bilinear up-sampling its nn.Upsample + F.pad (unet_parts.py:80,85-88)
+        are the ONLY reader, so the producer block is told the skip's extent and returns the up-sampled tensor itself -- one
+        kernel with its last BatchNorm + ReLU in training (csrc/pool_up.hip), the separate up-sampling kernel otherwise."""
+        if not getattr(self, f"up{j}").bilinear:
+            return None
+        s = skips[self.depth - j]
+        return ("up", int(s.shape[1]), int(s.shape[2]))
 
     def forward(self, x):
         dt = ops.compute_dtype(self.compute_dtype)

@@ -35,13 +35,19 @@ def _pad_c(t, cpad: int):
     return t if c == cpad else torch.nn.functional.pad(t, (0, cpad - c))
 
 
+def _is_up(tail) -> bool:
+    return isinstance(tail, tuple) and len(tail) == 3 and tail[0] == "up"
+
+
 def _finish_tail(z, tail):
     """The consumer of a DoubleConv's output as separate kernels: None -> z; "pool" -> (z as skip, maxpool2(z));
-    an OutConv -> its logits."""
+    ("up", Ho, Wo) -> bilinear x2 + zero padding to Ho x Wo (the next Up block's nn.Upsample + F.pad); an OutConv -> its logits."""
     if tail is None:
         return z
     if tail == "pool":
         return ops.PoolSplitFn.apply(z)
+    if _is_up(tail):
+        return ops.UpsampleBilinearPadFn.apply(z, tail[1], tail[2])
     return tail.nhwc(z)
 
 
@@ -80,6 +86,8 @@ def _conv_bn_relu(x0, x1, conv: nn.Conv2d, bn: nn.BatchNorm2d, training: bool, k
             return ops.ConvBnReluFn.apply(*args, ops.TAIL_POOL, None, None, False, pre_coef, *link)
         if training and isinstance(tail, OutConv) and ops.head_tail_ok(x0, Cout, tail.conv.weight):
             return ops.ConvBnReluFn.apply(*args, ops.TAIL_HEAD, tail.conv.weight, tail.conv.bias, False, pre_coef, *link)
+        if training and _is_up(tail) and ops.up_tail_ok(x0, Cout, tail[1], tail[2]):
+            return ops.ConvBnReluFn.apply(*args, ops.TAIL_UP, None, None, False, pre_coef, *link, (tail[1], tail[2]))
         return _finish_tail(ops.ConvBnReluFn.apply(*args, ops.TAIL_NONE, None, None, False, pre_coef, *link), tail)
     if defer or pre_coef is not None:
         raise RuntimeError("a deferred BatchNorm+ReLU needs 64-aligned layers (ops.pre_fuse_ok)")
@@ -131,7 +139,9 @@ class DoubleConv(nn.Module):
 
     def nhwc(self, x0, x1=None, tail=None):
         """`tail`: what consumes the block's output -- None (returns it), "pool" (returns (output, maxpool2(output)):
-        unet_parts.py:32 of the next Down) or the network's OutConv (returns its logits)."""
+        unet_parts.py:32 of the next Down), ("up", Ho, Wo) (returns the output up-sampled x2 and zero-padded to Ho x Wo:
+        unet_parts.py:80,85-88 of the next bilinear Up, which is then called with upsampled=True) or the network's OutConv
+        (returns its logits)."""
         seq = self.double_conv
         mid = seq[0].weight.shape[0]
         w1, w2 = seq[0].weight, seq[3].weight
@@ -190,9 +200,14 @@ class Up(nn.Module):
         self.use_attention = False
         self.attention = nn.Identity()
 
-    def nhwc(self, x1, x2, tail=None):
+    def nhwc(self, x1, x2, tail=None, upsampled: bool = False):
+        """`upsampled`: x1 already is the up-sampled, padded tensor (its producer ran with tail=("up", Ho, Wo))."""
         Ho, Wo = x2.shape[1], x2.shape[2]
-        if self.bilinear:
+        if upsampled:
+            if not self.bilinear or tuple(x1.shape[1:3]) != (Ho, Wo):
+                raise RuntimeError("Up.nhwc(upsampled=True) needs a bilinear block and an input of the skip's extent")
+            u = x1
+        elif self.bilinear:
             u = ops.UpsampleBilinearPadFn.apply(x1, Ho, Wo)
         else:
             u = ops.ConvTranspose2x2PadFn.apply(x1, self.up.weight, self.up.bias, Ho, Wo)
