@@ -110,13 +110,15 @@ def cpu_baseline(size: int):
                                         "timing only, the fixtures pin the fp32 leg"}}
 
 
-def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, hip_seeds=(0, 1, 2)):
+def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, hip_seeds=(0, 1, 2, 3, 4)):
     """BASELINE metric's second half, "Dice vs ref": the same `steps` train steps of UNet_T(1,1,bilinear) on seeded
     synthetic ellipse batches run by the CPU oracle (reference restatement) and by the HIP path (fp32 and bf16), then the
     evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here).
-    RMSprop's sign-like steps make the path to the plateau chaotic: last-bit differences move the Dice after 200 steps by
-    several points (scratch/dice_chaos2.py: 0.91-0.99 over 8 initialisations for one and the same binary), so the HIP
-    figures are means over `hip_seeds` initialisations (the first is the oracle's own initial state)."""
+    RMSprop's sign-like steps (momentum 0.999, batch 4) make the path to the plateau chaotic AND bumpy: last-bit differences
+    move the Dice after 200 steps by several points, and a single trajectory dips and recovers (scratch/dice_chaos3.py, one binary,
+    Dice at 150 / 175 / 200 / 225 / 250 steps: bf16 seed 0 0.90 / 0.90 / 0.85 / 0.97 / 0.98, bf16 seed 4 0.96 / 0.93 / 0.77 / 0.91 /
+    0.94, fp32 seed 4 0.96 / 0.96 / 0.94 / 0.89 / 0.89, the other nine runs 0.97-0.98 throughout).  The HIP figures are therefore the
+    MEDIAN over `hip_seeds` initialisations (the first is the oracle's own initial state) with every run and the mean beside it."""
     import unet_amd
     from oracle import step_ref as S
     from oracle import unet_ref as U
@@ -150,7 +152,8 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
             d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp, postprocess=False)
             runs.append(round(float(d), 4))
             stepper.optimizer.close()
-        out[name] = round(sum(runs) / len(runs), 4)
+        out[name] = sorted(runs)[len(runs) // 2]
+        out[name + "_mean"] = round(sum(runs) / len(runs), 4)
         out[name + "_runs"] = runs
     return out
 

@@ -400,10 +400,13 @@ def test_dice_after_training_matches_oracle():
     r = bench.dice_vs_ref()
     _REPORT.append(f"dice_vs_ref {r}")
     assert r["ref_cpu_fp32"] > 0.9, r                      # the task is learned
-    # HIP figures are means over three initialisations (the path to the plateau is chaotic: bench.dice_vs_ref)
-    assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.04, r
-    assert abs(r["hip_bf16"] - r["ref_cpu_fp32"]) < 0.06, r
-    assert min(r["hip_fp32_runs"] + r["hip_bf16_runs"]) > 0.8, r
+    # HIP figures are medians over five initialisations: the path to the plateau is chaotic and single trajectories dip and
+    # recover (bench.dice_vs_ref quotes scratch/dice_chaos3.py: 0.77-0.85 at step 200 on two of twelve runs that read 0.94-0.98
+    # fifty steps later), so the median is held to the oracle and a single run only to "has learned the task"
+    assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.02, r
+    assert abs(r["hip_bf16"] - r["ref_cpu_fp32"]) < 0.03, r
+    assert min(r["hip_fp32_runs"] + r["hip_bf16_runs"]) > 0.7, r
+    assert sum(1 for d in r["hip_fp32_runs"] + r["hip_bf16_runs"] if d > 0.95) >= 6, r
 
 
 def test_cc_loss_option_adds_value_only():
