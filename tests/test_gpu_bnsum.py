@@ -166,3 +166,50 @@ def test_train_steps_with_and_without_the_fused_sums(bilinear, size):
     # trajectory check, as in the golden trajectories of test_gpu_parity.py)
     # every DoubleConv but the stem's (recomputed output: its own kernels) hands its first BatchNorm's sums to backward-data
     assert calls[False] - calls[True] == 3 * 8, calls
+
+
+def test_second_consumer_of_the_activation_falls_back_to_the_reduce_pass():
+    """The sums that come with backward-data belong to ONE gradient tensor.  When the activation between the two convs has a second
+    reader, autograd hands the first layer the SUM of two gradients (another tensor): the link must be ignored and the reduce pass
+    must run on what arrived -- same gradients as with the fusion switched off, bit for bit (both legs then run the same kernels)."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, H, W, C = 2, 48, 40, 64
+    x = torch.randn(B, H, W, C, generator=g).to(dev, torch.bfloat16)
+    side = torch.randn(B, H, W, C, generator=g).to(dev, torch.bfloat16)
+    cot = torch.randn(B, H, W, C, generator=g).to(dev, torch.bfloat16)
+
+    def run(fuse, second_reader):
+        torch.manual_seed(4)
+        c1 = torch.nn.Conv2d(C, C, 3, padding=1, bias=False).to(dev)
+        b1 = torch.nn.BatchNorm2d(C).to(dev)
+        c2 = torch.nn.Conv2d(C, C, 3, padding=1, bias=False).to(dev)
+        b2 = torch.nn.BatchNorm2d(C).to(dev)
+        old = ops.FUSE_BNSUM
+        ops.FUSE_BNSUM = fuse
+        n0 = _count_reduce()
+        try:
+            link = ops.BnSumLink() if fuse else None
+            xin = x.clone().requires_grad_(True)
+            z1 = ops.ConvBnReluFn.apply(xin, None, c1.weight, b1.weight, b1.bias, b1.running_mean, b1.running_var, b1.num_batches_tracked,
+                                        True, 0.1, 1e-5, ops.TAIL_NONE, None, None, False, None, link, None)
+            z2 = ops.ConvBnReluFn.apply(z1, None, c2.weight, b2.weight, b2.bias, b2.running_mean, b2.running_var, b2.num_batches_tracked,
+                                        True, 0.1, 1e-5, ops.TAIL_NONE, None, None, False, None, None, link)
+            loss = (z2.float() * cot.float()).sum()
+            if second_reader:
+                loss = loss + (z1.float() * side.float()).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.FUSE_BNSUM = old
+        return [t.grad.float().clone() for t in (xin, c1.weight, b1.weight, b1.bias, c2.weight)], _count_reduce() - n0
+
+    ref, n_ref = run(False, True)
+    got, n_got = run(True, True)
+    assert n_ref == 2 and n_got == 2, (n_ref, n_got)              # both BatchNorm layers ran their own reduce pass
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # ... and without the second reader the first layer's reduce pass is gone
+    _, n_fused = run(True, False)
+    assert n_fused == 1, n_fused
