@@ -1221,34 +1221,79 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                         }
                 }
             }
-            // one channel at a time (3 live temporaries instead of 3 per channel: the epilogue runs at the register limit)
+            // Two channels at a time, as packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32: the accumulators of channels j, j + 1 of a
+            // pixel are an aligned register pair): half the VALU instructions of the scalar form -- the statistics were 10 % of a
+            // wave's lifetime on the K = 1152 layers (profiles/r03_conv_phase_stamps.txt) -- at six live temporaries.
+            if constexpr (!WRES) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int n = 0; n < NBW; ++n) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[ch(kg, n, 0)]);      // same-wave LDS write -> read: in order
+                for (int n = 0; n < NBW; ++n) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[ch(kg, n, 0)]);      // same-wave LDS write -> read: in order
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float pv = q[j];
-                    float s1 = 0.f, s2 = 0.f;
-                    if (full) {
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        const f32x2 pv = {q[jp], q[jp + 1]};
+                        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                        if (full) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float d = acc[i][n][j] - pv;
-                            s1 += d;
-                            s2 = fmaf(d, d, s2);
+                            for (int i = 0; i < 16; ++i) {
+                                const f32x2 v = {acc[i][n][jp], acc[i][n][jp + 1]};
+                                const f32x2 d = v - pv;
+                                s1 += d;
+                                s2 = __builtin_elementwise_fma(d, d, s2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const bool in = (i < vy) && (gx < W);
+                                const f32x2 v = {acc[i][n][jp], acc[i][n][jp + 1]};
+                                f32x2 d = v - pv;
+                                d[0] = in ? d[0] : 0.f;
+                                d[1] = in ? d[1] : 0.f;
+                                s1 += d;
+                                s2 = __builtin_elementwise_fma(d, d, s2);
+                            }
                         }
-                    } else {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float d = ((i < vy) && (gx < W)) ? acc[i][n][j] - pv : 0.f;
-                            s1 += d;
-                            s2 = fmaf(d, d, s2);
+                        for (int e = 0; e < 2; ++e) {
+                            const float a1 = uh_row16_sum(s1[e]), a2 = uh_row16_sum(s2[e]);   // lanes of one kg = one DPP row
+                            if (lx == 0) {
+                                const int cl = ch(kg, n, jp + e);
+                                S1[cl] += a1;
+                                S2[cl] += a2;
+                            }
                         }
                     }
-                    const float a1 = uh_row16_sum(s1), a2 = uh_row16_sum(s2);   // lanes of one kg = one DPP row
-                    if (lx == 0) {
-                        const int cl = ch(kg, n, j);
-                        S1[cl] += a1;
-                        S2[cl] += a2;
+                }
+            } else {
+                // (the weight-resident instantiation has no six registers to spare here: one channel at a time, 3 live temporaries)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(&PV[ch(kg, n, 0)]);      // same-wave LDS write -> read: in order
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pv = q[j];
+                        float s1 = 0.f, s2 = 0.f;
+                        if (full) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const float d = acc[i][n][j] - pv;
+                                s1 += d;
+                                s2 = fmaf(d, d, s2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const float d = ((i < vy) && (gx < W)) ? acc[i][n][j] - pv : 0.f;
+                                s1 += d;
+                                s2 = fmaf(d, d, s2);
+                            }
+                        }
+                        const float a1 = uh_row16_sum(s1), a2 = uh_row16_sum(s2);   // lanes of one kg = one DPP row
+                        if (lx == 0) {
+                            const int cl = ch(kg, n, j);
+                            S1[cl] += a1;
+                            S2[cl] += a2;
+                        }
                     }
                 }
             }
