@@ -1146,6 +1146,19 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                 const int c0 = co_blk + ch(kg, 0, 0);
                 const bool inr = gx < W && c0 < Coutv;
                 const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
+                if (full) {
+                    // interior tile (wave-uniform): one running offset, no per-row test / select / multiply -- the store section was
+                    // 9 % of a wave's lifetime on the K = 1152 layers (profiles/r03_conv_phase_stamps.txt).  An out-of-range lane
+                    // (narrow tensors) stays out of range: OOB_OFFSET + 16 rows is far from wrapping.
+                    unsigned vo = inr ? voff + (unsigned)sbase : OOB_OFFSET;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
+                                    (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, vo, 0, 0);
+                        vo += (unsigned)rbytes;
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (i < vy) {
@@ -1154,12 +1167,14 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, inr ? voff + (unsigned)(sbase + i * rbytes) : OOB_OFFSET, 0, 0);
                     }
                 }
+                }
             } else if (perm1) {
                 // rows i, i+1: after the half-wave swap lanes 0..31 hold 8 channels of row i, lanes 32..63 of row i+1
                 const int c0 = co_blk + wave * 16 + (kg & 1) * 8;
                 const int rsel = kg >> 1;
                 const bool inr = gx < W && c0 < Coutv;
                 const unsigned voff0 = (unsigned)((gx * ldy + c0) * ES + rsel * rbytes);
+                unsigned vo_run = inr ? voff0 + (unsigned)sbase : OOB_OFFSET;      // interior tiles: one running offset (see above)
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     bf16x4 a = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3]};
@@ -1168,7 +1183,10 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                     auto r0 = __builtin_amdgcn_permlane32_swap(au[0], bu[0], false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(au[1], bu[1], false, false);
                     const u32x4 o = u32x4{r0[0], r1[0], r0[1], r1[1]};
-                    if (i < vy) {          // (vy odd: the row i+1 half of the last pair is dropped per lane)
+                    if (full) {
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsy, vo_run, 0, 0);
+                        vo_run += 2u * (unsigned)rbytes;
+                    } else if (i < vy) {          // (vy odd: the row i+1 half of the last pair is dropped per lane)
                         const unsigned voff = (inr && i + rsel < vy) ? voff0 + (unsigned)(sbase + i * rbytes) : OOB_OFFSET;
                         __builtin_amdgcn_raw_buffer_store_b128(o, rsy, voff, 0, 0);
                     }
