@@ -94,7 +94,7 @@ def main():
         xo = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
         nslab = base.query("uh_conv3x3_stat_slabs", B, H, W, Cin, Cout, dt)
         stats = torch.empty(nslab * (2 * Cout + 2), dtype=torch.float32, device=dev)
-        dw = torch.empty(Cout * 9 * Cout, dtype=torch.float32, device=dev)
+        dw = torch.empty(Cout * 9 * max(Cin, Cout), dtype=torch.float32, device=dev)      # (conv1's result is Cout x 9 x Cin: larger than conv2's when Cin > Cout)
         wsb = max(base.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cout, Cout, dt), base.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout, dt))
         # every variant may plan a different workspace: take the largest
         for _, lb in libs:

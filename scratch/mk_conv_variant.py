@@ -3,6 +3,7 @@
 into scratch/ab/lib_<name>.so -- same C ABI, load it with UH_LIB_PATH or scratch/ab_conv.py):
     python scratch/mk_conv_variant.py diag      s_memtime stamps per phase of conv3x3_fwd_mfma_v2 + uh_diag_set(ptr)   (scratch/diag_phases.py)
     python scratch/mk_conv_variant.py diagmin   entry / exit stamps only (in-kernel clock and wave lifetimes of the unperturbed schedule)
+    python scratch/mk_conv_variant.py wgdiag    backward-weights: stamps at entry / first fence / end of the tile loop / slab stores drained   (scratch/diag_wgrad.py)
     python scratch/mk_conv_variant.py prio      the workgroup that has finished fewer tiles gets the higher issue priority (s_setprio)
     python scratch/mk_conv_variant.py young     the second half of the grid (dispatched last) gets issue priority
     python scratch/mk_conv_variant.py split31   launches with two tiles per workgroup: first half of the lanes three tiles, second half one"""
@@ -46,6 +47,32 @@ def variant(name, s):
                 "        unsigned long long* o = uh_diag_buf + ((size_t)blockIdx.x * 4 + wv) * 66;\n"
                 "        if (ln < diag_i && ln < 64) o[2 + ln] = diag_st[wv][ln];\n"
                 "        if (ln == 0) { o[0] = (unsigned long long)diag_i; o[1] = __builtin_amdgcn_s_memrealtime() - diag_r0; }\n    }\n" + g)
+    elif name == "wgdiag":
+        # backward-weights: entry, behind the first fence, behind the tile loop, behind the slab stores (per wave)
+        s = rep(s, "constexpr int PRE_MAX_C = 512;", "__device__ unsigned long long* uh_diag_buf = nullptr;\n"
+                'extern "C" int uh_diag_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(uh_diag_buf), &p, sizeof(p)); }\nconstexpr int PRE_MAX_C = 512;')
+        k = s.index("void conv3x3_wgrad_mfma_v2(")
+        a = "    const int tid = threadIdx.x, lane = tid & 63;\n"
+        j = s.index(a, k)
+        s = s[:j] + a + "    unsigned long long dg[4]; const unsigned long long dg_r0 = __builtin_amdgcn_s_memrealtime(); dg[0] = __builtin_amdgcn_s_memtime();\n" + s[j + len(a):]
+        b = "    tile_fence(t_begin, 0, t_begin < t_end);\n    int bufi = 0;\n"
+        j = s.index(b, k)
+        s = s[:j] + b + "    dg[1] = __builtin_amdgcn_s_memtime();\n" + s[j + len(b):]
+        f = "        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);\n    }\n"
+        j = s.index(f, k)
+        s = s[:j] + "        { const unsigned long long f0 = __builtin_amdgcn_s_memtime();\n        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);\n" \
+            "        dg_fence += __builtin_amdgcn_s_memtime() - f0; }\n    }\n" + s[j + len(f):]
+        s = s.replace("unsigned long long dg[4]; const unsigned long long dg_r0", "unsigned long long dg[4]; unsigned long long dg_fence = 0; const unsigned long long dg_r0", 1)
+        c = "    float* slab = slabs + (int64_t)split * Cout * 9 * Cin;\n#if UH_WGRAD_M16\n"
+        j = s.index(c, k)
+        s = s[:j] + "    dg[2] = __builtin_amdgcn_s_memtime();\n" + c + s[j + len(c):]
+        # end of kernel: the closing of the #else / #endif slab store
+        d = "            slab[((int64_t)co * 9 + tap) * Cin + ci] = acc[tap][reg];\n        }\n#endif\n}"
+        j = s.index(d, k)
+        s = s[:j] + "            slab[((int64_t)co * 9 + tap) * Cin + ci] = acc[tap][reg];\n        }\n#endif\n" \
+            "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    dg[3] = __builtin_amdgcn_s_memtime();\n" \
+            "    if (uh_diag_buf && lane == 0) {\n        unsigned long long* o = uh_diag_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (tid >> 6)) * 8;\n" \
+            "        o[0] = 4; o[1] = __builtin_amdgcn_s_memrealtime() - dg_r0; o[2] = dg[0]; o[3] = dg[1]; o[4] = dg[2]; o[5] = dg[3]; o[6] = (unsigned long long)(t_end - t_begin); o[7] = dg_fence;\n    }\n}" + s[j + len(d):]
     elif name == "prio":
         s = rep(s, loop, "    int tiles_done = 0;\n" + loop + "\n        if (tiles_done == 0) __builtin_amdgcn_s_setprio(3);\n"
                 "        else if (tiles_done == 1) __builtin_amdgcn_s_setprio(2);\n        else if (tiles_done == 2) __builtin_amdgcn_s_setprio(1);\n"

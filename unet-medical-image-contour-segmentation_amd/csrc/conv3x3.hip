@@ -2656,8 +2656,10 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+#if !UH_WGRAD_M16
         if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
         auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
@@ -2684,6 +2686,13 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         };
         ld_d(0);
         ld_x(0);
+        // The next tile's DMA (ten pieces per thread, ~150 VALU instructions of address arithmetic) is issued HERE, behind the tile's
+        // first fragment reads: at the top of the tile that arithmetic ran in front of them, with every wave of the workgroup just
+        // released from the barrier and the matrix pipe empty; now it runs under the LDS latency of the reads the first MFMAs wait
+        // for (profiles/r03_wgrad_phase_stamps.txt).  The buffer it writes was released by the barrier at the end of the last tile.
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             if (a + 1 < 6) ld_x(a + 1);
