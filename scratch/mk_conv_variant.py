@@ -4,6 +4,7 @@ into scratch/ab/lib_<name>.so -- same C ABI, load it with UH_LIB_PATH or scratch
     python scratch/mk_conv_variant.py diag      s_memtime stamps per phase of conv3x3_fwd_mfma_v2 + uh_diag_set(ptr)   (scratch/diag_phases.py)
     python scratch/mk_conv_variant.py diagmin   entry / exit stamps only (in-kernel clock and wave lifetimes of the unperturbed schedule)
     python scratch/mk_conv_variant.py wgdiag    backward-weights: stamps at entry / first fence / end of the tile loop / slab stores drained   (scratch/diag_wgrad.py)
+    python scratch/mk_conv_variant.py nwr2      backward-weights with 4-wave workgroups (two per CU) on every layer
     python scratch/mk_conv_variant.py prio      the workgroup that has finished fewer tiles gets the higher issue priority (s_setprio)
     python scratch/mk_conv_variant.py young     the second half of the grid (dispatched last) gets issue priority
     python scratch/mk_conv_variant.py split31   launches with two tiles per workgroup: first half of the lanes three tiles, second half one"""
@@ -73,6 +74,9 @@ def variant(name, s):
             "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    dg[3] = __builtin_amdgcn_s_memtime();\n" \
             "    if (uh_diag_buf && lane == 0) {\n        unsigned long long* o = uh_diag_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + (tid >> 6)) * 8;\n" \
             "        o[0] = 4; o[1] = __builtin_amdgcn_s_memrealtime() - dg_r0; o[2] = dg[0]; o[3] = dg[1]; o[4] = dg[2]; o[5] = dg[3]; o[6] = (unsigned long long)(t_end - t_begin); o[7] = dg_fence;\n    }\n}" + s[j + len(d):]
+    elif name == "nwr2":
+        # backward-weights: 4-wave workgroups (64 x 64 channel tiles, two per CU) on every layer
+        s = rep(s, "        if (wide && sizeof(T) == 2 && Cout % 128 == 0 && !half_cu) p.nwr = 4;", "        (void)wide;")
     elif name == "prio":
         s = rep(s, loop, "    int tiles_done = 0;\n" + loop + "\n        if (tiles_done == 0) __builtin_amdgcn_s_setprio(3);\n"
                 "        else if (tiles_done == 1) __builtin_amdgcn_s_setprio(2);\n        else if (tiles_done == 2) __builtin_amdgcn_s_setprio(1);\n"
