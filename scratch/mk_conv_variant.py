@@ -5,6 +5,7 @@ into scratch/ab/lib_<name>.so -- same C ABI, load it with UH_LIB_PATH or scratch
     python scratch/mk_conv_variant.py diagmin   entry / exit stamps only (in-kernel clock and wave lifetimes of the unperturbed schedule)
     python scratch/mk_conv_variant.py wgdiag    backward-weights: stamps at entry / first fence / end of the tile loop / slab stores drained   (scratch/diag_wgrad.py)
     python scratch/mk_conv_variant.py nwr2      backward-weights with 4-wave workgroups (two per CU) on every layer
+    python scratch/mk_conv_variant.py nbw1      forward / backward-data with 16 channels per wave (three workgroups per CU) on every layer
     python scratch/mk_conv_variant.py prio      the workgroup that has finished fewer tiles gets the higher issue priority (s_setprio)
     python scratch/mk_conv_variant.py young     the second half of the grid (dispatched last) gets issue priority
     python scratch/mk_conv_variant.py split31   launches with two tiles per workgroup: first half of the lanes three tiles, second half one"""
@@ -77,6 +78,10 @@ def variant(name, s):
     elif name == "nwr2":
         # backward-weights: 4-wave workgroups (64 x 64 channel tiles, two per CU) on every layer
         s = rep(s, "        if (wide && sizeof(T) == 2 && Cout % 128 == 0 && !half_cu) p.nwr = 4;", "        (void)wide;")
+    elif name == "nbw1":
+        # forward / backward-data: the 64-channel-slab instantiation (16 channels per wave, 168 registers, THREE workgroups per CU) on every layer
+        s = s.replace("if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {", "if (false) {")
+        s = s.replace("    if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) { r.nbw = 2;", "    if (false) { r.nbw = 2;")
     elif name == "prio":
         s = rep(s, loop, "    int tiles_done = 0;\n" + loop + "\n        if (tiles_done == 0) __builtin_amdgcn_s_setprio(3);\n"
                 "        else if (tiles_done == 1) __builtin_amdgcn_s_setprio(2);\n        else if (tiles_done == 2) __builtin_amdgcn_s_setprio(1);\n"
