@@ -117,7 +117,8 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
     RMSprop's sign-like steps (momentum 0.999, batch 4) make the path to the plateau chaotic AND bumpy: last-bit differences
     move the Dice after 200 steps by several points, and a single trajectory dips and recovers (scratch/dice_chaos3.py, one binary,
     Dice at 150 / 175 / 200 / 225 / 250 steps: bf16 seed 0 0.90 / 0.90 / 0.85 / 0.97 / 0.98, bf16 seed 4 0.96 / 0.93 / 0.77 / 0.91 /
-    0.94, fp32 seed 4 0.96 / 0.96 / 0.94 / 0.89 / 0.89, the other nine runs 0.97-0.98 throughout).  The HIP figures are therefore the
+    0.94, fp32 seed 4 0.96 / 0.96 / 0.94 / 0.89 / 0.89, the other nine runs 0.97-0.98 throughout; the CPU oracle itself slides from
+    0.92 to 0.74 on seed 4: scratch/dice_chaos_oracle.py).  The HIP figures are therefore the
     MEDIAN over `hip_seeds` initialisations (the first is the oracle's own initial state) with every run and the mean beside it."""
     import unet_amd
     from oracle import step_ref as S
