@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="one GPU: replay the whole step from a captured HIP graph (GraphedTrainStepper)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the global-batch-32 leg (strong_gb32)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--no-b4-leg", action="store_true", help="N = 1: skip the 4-images-per-GPU leg (per_gpu_batch4)")
     ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only inference timing (clean train-step profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -110,16 +111,16 @@ def cpu_baseline(size: int):
                                         "timing only, the fixtures pin the fp32 leg"}}
 
 
-def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, hip_seeds=(0, 1, 2, 3, 4)):
-    """BASELINE metric's second half, "Dice vs ref": the same `steps` train steps of UNet_T(1,1,bilinear) on seeded
-    synthetic ellipse batches run by the CPU oracle (reference restatement) and by the HIP path (fp32 and bf16), then the
-    evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle is the checker here).
-    RMSprop's sign-like steps (momentum 0.999, batch 4) make the path to the plateau chaotic AND bumpy: last-bit differences
-    move the Dice after 200 steps by several points, and a single trajectory dips and recovers (scratch/dice_chaos3.py, one binary,
-    Dice at 150 / 175 / 200 / 225 / 250 steps: bf16 seed 0 0.90 / 0.90 / 0.85 / 0.97 / 0.98, bf16 seed 4 0.96 / 0.93 / 0.77 / 0.91 /
-    0.94, fp32 seed 4 0.96 / 0.96 / 0.94 / 0.89 / 0.89, the other nine runs 0.97-0.98 throughout; the CPU oracle itself slides from
-    0.92 to 0.74 on seed 4: scratch/dice_chaos_oracle.py).  The HIP figures are therefore the
-    MEDIAN over `hip_seeds` initialisations (the first is the oracle's own initial state) with every run and the mean beside it."""
+def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, seeds=(0, 1, 2, 3, 4), extra=(225, 250)):
+    """BASELINE metric's second half, "Dice vs ref", like for like: the same train steps of UNet_T(1,1,bilinear) on seeded
+    synthetic ellipse batches run by the CPU oracle (reference restatement, fp32) and by the HIP path (fp32 and bf16) from the
+    SAME five initialisations, then the evaluate.py Dice of each on a held-out batch.  Part of the cpu_baseline leg (the oracle
+    is the checker here).  RMSprop's sign-like steps (momentum 0.999, batch 4) make the path to the plateau chaotic AND bumpy for
+    the reference recipe itself: last-bit differences move the Dice after 200 steps by several points and single trajectories
+    dip and recover (profiles/r04_dice_chaos_oracle.txt: the oracle reads 0.98 throughout on three initialisations, 0.95 on one and
+    slides 0.92 / 0.87 / 0.92 / 0.86 / 0.86 / 0.74 over steps 150 ... 300 on seed 4).  So every figure is reported per run, the
+    headline figures are MEDIANS over the initialisations, and beside the Dice at `steps` each run carries the mean of its Dice
+    at `steps` and the `extra` checkpoints (a dip at one checkpoint moves that figure by a third)."""
     import unet_amd
     from oracle import step_ref as S
     from oracle import unet_ref as U
@@ -127,36 +128,73 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
     widths = (8, 16, 32, 64, 128)                                  # UNet_T (unet_model.py:52-82)
     train = [unet_amd.ellipse_batch(batch, size, seed=100 + i) for i in range(4)]
     held = unet_amd.ellipse_batch(8, size, seed=7)
-    st = U.init_state(1, 1, True, widths=widths, seed=0)
-    init = {k: v.clone() for k, v in st.items()}
-    opt = None
-    for i in range(steps):
-        im, mk = train[i % len(train)]
-        st, opt, _ = S.train_step(st, opt, im, mk, n_classes=1, bilinear=True, lr=lr)
-    d_ref, _ = S.evaluate_dice(st, held[0], held[1], n_classes=1, bilinear=True)
-    out = {"model": f"UNet_T(1,1,bilinear) {batch}x1x{size}x{size}", "steps": steps, "lr": lr, "ref_cpu_fp32": round(float(d_ref), 4)}
+    marks = (steps,) + tuple(extra)
+    inits = {seed: U.init_state(1, 1, True, widths=widths, seed=seed) for seed in seeds}
+
+    def med(v):
+        return sorted(v)[len(v) // 2]
+
+    out = {"model": f"UNet_T(1,1,bilinear) {batch}x1x{size}x{size}", "steps": steps, "lr": lr, "seeds": list(seeds),
+           "avg_checkpoints": list(marks)}
+    t0 = time.perf_counter()
+    at, avg = [], []
+    for seed in seeds:
+        st, opt, ds = {k: v.clone() for k, v in inits[seed].items()}, None, []
+        for i in range(max(marks)):
+            im, mk = train[i % len(train)]
+            st, opt, _ = S.train_step(st, opt, im, mk, n_classes=1, bilinear=True, lr=lr)
+            if i + 1 in marks:
+                ds.append(float(S.evaluate_dice(st, held[0], held[1], n_classes=1, bilinear=True)[0]))
+        at.append(round(ds[0], 4))
+        avg.append(round(sum(ds) / len(ds), 4))
+    out.update({"ref_cpu_fp32": med(at), "ref_cpu_fp32_runs": at, "ref_cpu_fp32_avg": med(avg), "ref_cpu_fp32_avg_runs": avg,
+                "ref_cpu_seconds": round(time.perf_counter() - t0, 1)})
     dev = torch.device("cuda", torch.cuda.current_device())
+    held_set = [{"image": held[0], "mask": held[1]}]
     for name, amp in (("hip_fp32", False), ("hip_bf16", True)):
-        runs = []
-        for seed in hip_seeds:
+        at, avg = [], []
+        for seed in seeds:
             model = unet_amd.UNet_T(1, 1, bilinear=True)
-            if seed == hip_seeds[0]:
-                model.load_state_dict({k: v.clone() for k, v in init.items()})
-            else:
-                sd = U.init_state(1, 1, True, widths=widths, seed=seed)
-                model.load_state_dict({k: v.clone() for k, v in sd.items()})
+            model.load_state_dict({k: v.clone() for k, v in inits[seed].items()})
             model = model.to(dev)
             stepper = unet_amd.TrainStepper(model, lr=lr, amp=amp)
-            for i in range(steps):
+            ds = []
+            for i in range(max(marks)):
                 im, mk = train[i % len(train)]
                 stepper.step(im.to(dev), mk.to(dev))
-            d, _, _ = unet_amd.evaluate(model, [{"image": held[0], "mask": held[1]}], dev, amp=amp, postprocess=False)
-            runs.append(round(float(d), 4))
+                if i + 1 in marks:
+                    ds.append(float(unet_amd.evaluate(model, held_set, dev, amp=amp, postprocess=False)[0]))
+            at.append(round(ds[0], 4))
+            avg.append(round(sum(ds) / len(ds), 4))
             stepper.optimizer.close()
-        out[name] = sorted(runs)[len(runs) // 2]
-        out[name + "_mean"] = round(sum(runs) / len(runs), 4)
-        out[name + "_runs"] = runs
+        out[name] = med(at)
+        out[name + "_mean"] = round(sum(at) / len(at), 4)
+        out[name + "_runs"] = at
+        out[name + "_avg"] = med(avg)
+        out[name + "_avg_runs"] = avg
     return out
+
+
+def baseline_config(args, world: int, B: int, amp: bool, bilinear: bool) -> str:
+    """Which line of BASELINE.json's `configs` this run is (0-based index + its text's key words), or 'none' with the reason."""
+    gb = B * world
+    if args.config4:
+        return "configs[3]: 5-level UNet (64->1024), 3x1024x1024 in, 4 classes, bilinear" if args.size == 1024 else "none (config 4 at another size)"
+    if args.size != 512:
+        return "none (another image size)"
+    if not bilinear:
+        if not amp and args.cc_loss and gb == 16:
+            return f"configs[4]: transposed-conv upsample, fp32, connected_component_loss, batch=16 on {world} GPU(s) (BASELINE: 4)"
+        return "none (transposed-conv variant off config 5's recipe: needs --fp32 --cc-loss --global-batch 16)"
+    if amp and gb == 32:
+        return f"configs[2]: batch=32 data parallel on {world} GPU(s) (BASELINE: 8), gradient all-reduce"
+    if amp and world == 1 and B == 8:
+        return "configs[1]: UNet bf16 batch=8 on 1 GPU"
+    if amp and B == 8:
+        return f"configs[1] per GPU on {world} GPUs (weak scaling: 8 images per GPU)"
+    if not amp and world == 1 and B == 2:
+        return "configs[0] shape (batch=2, fp32) on the GPU (the reference's own leg is the CPU baseline)"
+    return "none"
 
 
 def launch_ranks(n: int) -> int:
@@ -353,24 +391,57 @@ def main():
         del im2, mk2
 
     # ---- dominant-kernel roofline, measured live with events on the launch stream (one extra step)
-    roof = None
-    kernels = None
-    if not args.no_kernel_profile:
-        # EVERY rank runs this extra step (it contains the gradient / loss-sum collectives); rank 0 records events
+    def profiled_step(im, mk):
+        """One extra step with HIP events around every conv launch on the launch stream.  EVERY rank runs it (it contains the
+        gradient / loss-sum collectives); rank 0 records.  -> {family: [calls, seconds, flops]}, [(name, flops, seconds, tag)]"""
         ops.PROFILE.clear()
         ops.PROFILE_ON = rank == 0
         side, stepper.wgrad_stream = stepper.wgrad_stream, None      # time every kernel alone on the launch stream
-        run_step(images, masks)
+        run_step(im, mk)
         torch.cuda.synchronize()
         stepper.wgrad_stream = side
         ops.PROFILE_ON = False
-    if rank == 0 and not args.no_kernel_profile:
+        launches = [(n, f, e0.elapsed_time(e1) * 1e-3, t) for n, f, e0, e1, t in ops.PROFILE]
+        ops.PROFILE.clear()
         agg = {}
-        for name, flops, e0, e1, _tag in ops.PROFILE:
+        for name, flops, sec, _tag in launches:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += sec
             a[2] += flops
+        return agg, launches
+
+    def down2_in_step(launches, nb):
+        """The six conv launches of the 256-channel DoubleConv (down2: 128 -> 256 -> 256 at a quarter of the image extent) where
+        they run in the timed workload: one events pair per launch inside the profiled train step, backward-weights including
+        its slab reduction, the BatchNorm / pooling kernels of the step between them."""
+        q = S // 4
+        want = {"fwd_conv1": ("fwd", nb, q, q, 128, 256), "fwd_conv2": ("fwd", nb, q, q, 256, 256),
+                "dgrad_conv2": ("dgrad", nb, q, q, 256, 256), "dgrad_conv1": ("dgrad", nb, q, q, 256, 128),
+                "wgrad_conv2": ("wgrad", nb, q, q, 256, 256), "wgrad_conv1": ("wgrad", nb, q, q, 128, 256)}
+        ins, tot_s, tot_f = {}, 0.0, 0.0
+        for key, tag in want.items():
+            # up2.3 (256 -> 128 at this extent) is a forward launch WITH statistics: the tag's direction tells it from
+            # down2's backward-data; exactly one launch carries each tag
+            hits = [(f, sec) for _n, f, sec, t in launches if t == tag]
+            if len(hits) != 1:
+                raise RuntimeError(f"{key}: {len(hits)} launches tagged {tag}")
+            f, sec = hits[0]
+            ins[key] = {"ms": round(sec * 1e3, 4), "tflops": round(f / sec / 1e12, 1)}
+            tot_s += sec
+            tot_f += f
+        ins["all_six"] = {"ms": round(tot_s * 1e3, 4), "tflops": round(tot_f / tot_s / 1e12, 1),
+                          "frac_of_peak": round(tot_f / tot_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        ins["what"] = f"one launch each, inside the profiled train step at {nb} images per GPU (single events pair per launch)"
+        return ins
+
+    in_step_ok = amp and bilinear and not args.config4 and n_in == 1
+    roof = None
+    kernels = None
+    agg = launches = None
+    if not args.no_kernel_profile:
+        agg, launches = profiled_step(images, masks)
+    if rank == 0 and not args.no_kernel_profile:
         kernels = {k: {"calls": v[0], "ms": round(v[1] * 1e3, 3), "tflops": round(v[2] / v[1] / 1e12, 1) if v[1] > 0 else 0.0}
                    for k, v in agg.items()}
         dom = max(agg.items(), key=lambda kv: kv[1][1])
@@ -396,36 +467,33 @@ def main():
         roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
+        if args.fp32 and args.bf16x3 and dom[0].startswith("conv3x3_"):
+            # fp32 tensors, products on the bf16 matrix pipe as three bf16 products each (hi*hi + hi*lo + lo*hi): the pipe that
+            # bounds the kernel is the bf16 one and it executes 3x the algorithmic FLOPs -- quoted against THAT peak (dividing
+            # the algorithmic rate by the fp32 MFMA peak gave a "fraction" of 1.6: not a measurement)
+            roof.update({"peak": MFMA_BF16_PEAK_TFLOPS, "pipe_tflops": round(3 * ach, 1),
+                         "frac": round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "note": "achieved = algorithmic fp32 FLOP/s; frac = 3 x achieved / bf16 MFMA peak (bf16x3 split products)"})
+        # every launch of the forward / backward-data kernel, whatever its epilogue carries: the eight backward-data launches
+        # with the fused BatchNorm-backward sums are a family of their own above (their time includes a read of the BatchNorm
+        # input and the sums), so the plain family alone would flatter the kernel
+        fam = [v for k, v in agg.items() if k in ("conv3x3_fwd_mfma", "conv3x3_dgrad_bnsum_mfma")]
+        if dom[0] == "conv3x3_fwd_mfma" and fam:
+            f_all, s_all, n_all = sum(v[2] for v in fam), sum(v[1] for v in fam), sum(v[0] for v in fam)
+            roof["all_launches"] = {"launches_per_step": n_all, "ms": round(s_all * 1e3, 3),
+                                    "achieved": round(f_all / s_all / 1e12, 1)}
+            roof["all_launches_frac"] = round(f_all / s_all / 1e12 / peak, 4)
         # the layer the north-star names: the 256-channel DoubleConv (down2: 128->256->256 at 128x128, batch 8)
         try:
             kernels["double_conv_256"] = ops.bench_double_conv(B, S // 4, S // 4, 128, 256, torch.bfloat16 if amp else torch.float32)
         except Exception as e:                      # an optional extra must never cost the headline line
             kernels["double_conv_256"] = {"error": repr(e)}
-        # ... and the same six launches where they run in the timed workload: down2 of the profiled train step above (events
-        # around each launch, backward-weights including its slab reduction, the BatchNorm / pooling kernels of the step
-        # between them instead of twenty launches of one kernel back to back)
-        try:
-            q = S // 4
-            want = {"fwd_conv1": ("fwd", B, q, q, 128, 256), "fwd_conv2": ("fwd", B, q, q, 256, 256),
-                    "dgrad_conv2": ("dgrad", B, q, q, 256, 256), "dgrad_conv1": ("dgrad", B, q, q, 256, 128),
-                    "wgrad_conv2": ("wgrad", B, q, q, 256, 256), "wgrad_conv1": ("wgrad", B, q, q, 128, 256)}
-            ins, tot_s, tot_f = {}, 0.0, 0.0
-            for key, tag in want.items():
-                # up2.3 (256 -> 128 at this extent) is a forward launch WITH statistics: the tag's direction tells it from
-                # down2's backward-data; the first match in launch order is down2's for every other key
-                hits = [(f, e0.elapsed_time(e1) * 1e-3) for _n, f, e0, e1, t in ops.PROFILE if t == tag]
-                if len(hits) != 1:
-                    raise RuntimeError(f"{key}: {len(hits)} launches tagged {tag}")
-                f, sec = hits[0]
-                ins[key] = {"ms": round(sec * 1e3, 4), "tflops": round(f / sec / 1e12, 1)}
-                tot_s += sec
-                tot_f += f
-            ins["all_six"] = {"ms": round(tot_s * 1e3, 4), "tflops": round(tot_f / tot_s / 1e12, 1)}
-            ins["what"] = "one launch each, inside the profiled train step (single events pair per launch)"
-            if amp and bilinear and not args.config4 and n_in == 1:
-                kernels["double_conv_256_in_step"] = ins
-        except Exception as e:
-            kernels["double_conv_256_in_step"] = {"error": repr(e)}
+        # ... and the same six launches where they run in the timed workload: down2 of the profiled train step above
+        if in_step_ok:
+            try:
+                kernels["double_conv_256_in_step"] = down2_in_step(launches, B)
+            except Exception as e:
+                kernels["double_conv_256_in_step"] = {"error": repr(e)}
         # the same six kernels at the extent the layer has in BASELINE config 3's global batch (32 images): eight tiles per
         # resident workgroup instead of two, the 75 MB of backward-weights slabs amortised over 4x the pixels
         if amp and B == 8 and S == 512 and not args.config4:
@@ -433,6 +501,35 @@ def main():
                 kernels["double_conv_256_batch32"] = ops.bench_double_conv(32, S // 4, S // 4, 128, 256, torch.bfloat16, iters=10)
             except Exception as e:
                 kernels["double_conv_256_batch32"] = {"error": repr(e)}
+
+    # ---- N > 1: the kernel figure at the strong leg's per-GPU batch (config 3 runs 4 images per GPU on 8 GPUs)
+    if strong_gb32 is not None and not args.no_kernel_profile and in_step_ok:
+        b2 = strong_gb32["per_gpu_batch"]
+        im2, mk2 = make_batch(b2, 101 + rank)
+        _agg2, launches2 = profiled_step(im2, mk2)
+        if rank == 0:
+            try:
+                strong_gb32["double_conv_256_in_step"] = down2_in_step(launches2, b2)
+            except Exception as e:
+                strong_gb32["double_conv_256_in_step"] = {"error": repr(e)}
+        del im2, mk2
+
+    # ---- N = 1: config 3's per-GPU workload (4 images per GPU) on this GPU, so that the fixed per-step costs that decide the
+    # 1 -> 8 scaling of a fixed global batch are in the one-GPU record too
+    per_gpu_batch4 = None
+    if world == 1 and not strong and B == 8 and not args.config4 and not args.no_b4_leg:
+        im4, mk4 = make_batch(4, 201)
+        dt4, _, _ = measure(im4, mk4, args.steps, max(2, args.warmup))
+        per_gpu_batch4 = {"per_gpu_batch": 4, "steps": args.steps, "ms_per_step": round(dt4 / args.steps * 1e3, 3),
+                          "images_per_sec": round(4 * args.steps / dt4, 2),
+                          "vs_batch8_images_per_sec": round((4 * args.steps / dt4) / (B * args.steps / elapsed), 4)}
+        if not args.no_kernel_profile and in_step_ok:
+            _agg4, launches4 = profiled_step(im4, mk4)
+            try:
+                per_gpu_batch4["double_conv_256_in_step"] = down2_in_step(launches4, 4)
+            except Exception as e:
+                per_gpu_batch4["double_conv_256_in_step"] = {"error": repr(e)}
+        del im4, mk4
 
     # ---- sustained leg: a training job is minutes of back-to-back steps, the headline above is a 0.2 s window.  >= 2 s of
     # continuous steps (every rank takes part: the steps hold collectives), and the 256-channel DoubleConv timed again
@@ -464,6 +561,7 @@ def main():
             "config": {"workload": (f"UNet({n_in},{n_cls},bilinear={bilinear}{', depth 5' if args.config4 else ''}) train step "
                                     f"({'BCE' if n_cls == 1 else 'CE'}+Dice+boundary, clip 1.0, RMSprop), "
                                     f"{B} x {n_in}x{S}x{S} per GPU, global batch {B * world}"),
+                       "baseline_config": baseline_config(args, world, B, amp, bilinear),
                        "parallelism": f"dp{world}", "global_batch": B * world, "per_gpu_batch": B,
                        "bn": "global-batch statistics (SyncBN)" if args.sync_bn else "per-rank batch statistics",
                        "dice": "global-batch sums (all-reduced)"},
@@ -475,6 +573,8 @@ def main():
         }
         if strong_gb32 is not None:
             out["strong_gb32"] = strong_gb32
+        if per_gpu_batch4 is not None:
+            out["per_gpu_batch4"] = per_gpu_batch4
         if world > 1:
             import torch.distributed as dist
             out["collective"] = {

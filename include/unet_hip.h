@@ -141,7 +141,10 @@ int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
  * Results are bit-identical to the separate-kernel path.  bf16, one source of <= 512 channels (multiple of 64), Cout % 64 == 0,
  * tensors below 2 GiB: uh_conv3x3_pre_ok() says whether a call qualifies.  dt may carry UH_WFRAG in the forward call.
  * uh_conv3x3_wgrad_pre: backward-weights of such a layer (workspace: uh_conv3x3_wgrad_ws_bytes); backward-data is the
- * ordinary uh_conv3x3_fwd on dy with the transposed filter and yields the gradient of x. */
+ * ordinary uh_conv3x3_fwd on dy with the transposed filter and yields the gradient of x.
+ * BUILD FLAG: the kernel instantiations behind these two calls are compiled only with -DUH_BUILD_PRE=1 (build.py:
+ * UH_BUILD_PRE=1 -> libunet_hip_pre.so); measured a net loss on the train step, so the default library
+ * answers uh_conv3x3_pre_ok() with 0 and the two calls fail with UH_EINVAL and a message that says so. */
 int uh_conv3x3_pre_ok(int B, int H, int W, int C0, int Cout, int ld0, int ldy, int dt);
 int uh_conv3x3_fwd_pre(const void* x0, int C0, int ld0, const float* pre_scale, const float* pre_shift, const void* w,
                        void* y, int ldy, int Cout, float* stat_partials, int B, int H, int W, int dt, uh_stream stream);
@@ -368,6 +371,17 @@ int uh_dice_from_sums(const float* sums, int64_t ngroups, float eps, float* out,
  * total = bce_mean + dice_loss + w_boundary*boundary[0]; sums from uh_bce_dice_sums. */
 int uh_seg_loss_binary_finish(const float* sums, double n_mean, const float* boundary, float w_boundary,
                               float* out, uh_stream stream);
+/* train.py:119-134 for one process in three launches instead of six (+ the torch glue between them): one pass over the
+ * logits forms the BCE / Dice partial sums and the prediction's min / max (boundary_loss.py:28), the boundary counts follow,
+ * one block finishes.  logits fp32 [B][H][W] dense, mask int64 class ids, target = mask / mask_div.
+ * sums[0..3] as uh_bce_dice_sums writes them (uh_bce_dice_grad takes them); out[0..3] = { total, bce_mean, dice_loss,
+ * boundary } as uh_seg_loss_binary_finish writes them, out[4] = 1.0 when total is NaN (train.py:149), else 0.0.
+ * w_boundary == 0 skips the boundary term (out[3] = 0).  Bit-identical to the separate calls.  Data-parallel runs keep the
+ * separate calls (the sums are all-reduced between them).  ws: uh_seg_loss_fused_ws_bytes(). */
+size_t uh_seg_loss_fused_ws_bytes(void);
+int uh_seg_loss_binary_fused(const float* logits, const int64_t* mask, int mask_div, int B, int H, int W, int edge_width,
+                             float edge_weight, float smooth, float w_boundary, double n_mean, float* sums, float* out,
+                             void* ws, size_t ws_bytes, uh_stream stream);
 /* train.py:137-142: out = { total, ce_mean, dice_loss, boundary }, sums from uh_ce_dice_sums. */
 int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double n_mean, const float* boundary,
                                   float w_boundary, float* out, uh_stream stream);

@@ -33,6 +33,20 @@ def test_one_rank_line_is_unchanged():
     assert out["n_gpus"] == 1 and "collective" not in out and "strong_gb32" not in out
     assert out["scaling"] == "weak" and out["sustained"]["steps"] >= 2
     assert out["roofline"]["bound"] == "mfma" and "double_conv_256_after_sustained" in out["kernels"]
+    # every launch of the forward / backward-data kernel beside the plain family, and config 3's per-GPU batch on one GPU
+    assert 0 < out["roofline"]["all_launches_frac"] <= 1 and out["roofline"]["all_launches"]["launches_per_step"] == 34
+    b4 = out["per_gpu_batch4"]
+    assert b4["per_gpu_batch"] == 4 and b4["ms_per_step"] > 0 and 0 < b4["vs_batch8_images_per_sec"] < 2
+    assert b4["double_conv_256_in_step"]["all_six"]["tflops"] > 0
+
+
+def test_bf16x3_roofline_is_quoted_on_the_pipe_that_runs_it():
+    """fp32 tensors with bf16x3 split products: three bf16 MFMA products per algorithmic one, quoted against the bf16 peak -- the
+    fraction must be a fraction (round 3 divided by the fp32 peak: 1.59)."""
+    out = _bench(["--gpus", "1", "--fp32", "--bf16x3", "--no-sustained", "--no-b4-leg"] + COMMON)
+    r = out["roofline"]
+    assert r["peak"] == 2500.0 and 0 < r["frac"] <= 1.0, r
+    assert abs(r["pipe_tflops"] - 3 * r["achieved"]) < 0.5, r
 
 
 def test_two_ranks_over_gloo_on_one_gpu():
@@ -41,8 +55,40 @@ def test_two_ranks_over_gloo_on_one_gpu():
     assert out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
     sg = out["strong_gb32"]
     assert sg["global_batch"] == 32 and sg["per_gpu_batch"] == 16 and sg["ms_per_step"] > 0
+    assert sg["double_conv_256_in_step"]["all_six"]["tflops"] > 0           # the kernel figure at the strong leg's per-GPU batch
     assert out["collective"]["exposed_allreduce_ms_per_step"] is not None
     assert out["sustained"]["images_per_sec"] > 0
+
+
+def test_config5_recipe_through_the_two_rank_launcher():
+    """BASELINE config 5 exactly as the multi-GPU driver would start it (transposed-conv upsample, fp32, connected_component_loss,
+    global batch 16), at two ranks over gloo on the test GPU: the line names the config, carries the convT model's gradient
+    payload (124.15 MB) and the exposed all-reduce time.  Unmeasured over RCCL on this pool (one-GPU boxes)."""
+    out = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--convt", "--fp32", "--cc-loss", "--global-batch", "16",
+                  "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-inference", "--sustained-seconds", "0.05"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f32"
+    assert out["config"]["baseline_config"].startswith("configs[4]"), out["config"]
+    assert out["config"]["global_batch"] == 16 and out["config"]["per_gpu_batch"] == 8
+    assert "bilinear=False" in out["config"]["workload"] and "512x512" in out["config"]["workload"]
+    c = out["collective"]
+    assert c["world"] == 2 and abs(c["grad_bytes"] / 1e6 - 124.15) < 0.01, c
+    assert c["exposed_allreduce_ms_per_step"] is not None
+    assert out["loss"] == out["loss"]                                        # finite: the cc term is a Python float added to the value
+
+
+def test_config3_strong_leg_with_sync_bn_through_the_two_rank_launcher():
+    """BASELINE config 3's workload (global batch 32 over the ranks, bf16, bilinear) with global-batch BatchNorm statistics, at two
+    ranks over gloo on the test GPU: names the config, 69.05 MB of gradients per step, SyncBN stated in the line."""
+    out = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--global-batch", "32", "--sync-bn",
+                  "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-inference", "--sustained-seconds", "0.05"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "bf16"
+    assert out["config"]["baseline_config"].startswith("configs[2]"), out["config"]
+    assert out["config"]["global_batch"] == 32 and out["config"]["per_gpu_batch"] == 16
+    assert "SyncBN" in out["config"]["bn"]
+    c = out["collective"]
+    assert c["world"] == 2 and abs(c["grad_bytes"] / 1e6 - 69.05) < 0.01, c
+    assert c["exposed_allreduce_ms_per_step"] is not None
+    assert out["kernels"]["double_conv_256_in_step"]["all_six"]["tflops"] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs for an RCCL run")

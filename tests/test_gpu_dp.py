@@ -355,6 +355,61 @@ def test_bucketed_gradient_sync_runs_over_rccl_with_one_rank():
     assert loss == ref_loss and torch.equal(torch.from_numpy(p), ref_p)
 
 
+def _rccl_one_rank_syncbn_worker(rank, world, port, q, own_group):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["UH_DP_FORCE_SYNC"] = "1"
+        os.environ["UH_SYNCBN_OWN_GROUP"] = "1" if own_group else "0"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import unet_amd
+        torch.manual_seed(0)
+        model = unet_amd.UNet_S(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+        stepper = unet_amd.TrainStepper(model, lr=1e-4, amp=False, wgrad_stream=True, sync_bn=True)
+        assert stepper.sync_bn is not None and (stepper.bn_group is not None) == bool(own_group)
+        im, mk = unet_amd.ellipse_batch(4, 96, seed=3)
+        for _ in range(3):
+            t = stepper.step(im.to(dev), mk.to(dev))           # no global_batch: the batch-size all-reduce runs too
+        torch.cuda.synchronize()
+        out = (rank, "ok", stepper.optimizer.flat_p.cpu().numpy(), float(t["loss"].detach()))
+        stepper.close()                                        # destroys the BatchNorm communicator when there is one
+        assert stepper.bn_group is None
+        dist.barrier()                                         # the gradient communicator still works afterwards
+        q.put(out)
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("own_group", [False, True])
+def test_sync_bn_collectives_run_over_rccl_with_one_rank(own_group):
+    """SyncBN's all_gather / all_reduce per BatchNorm layer against the real backend (one-rank group, UH_DP_FORCE_SYNC=1), on the
+    gradient communicator (default) and on a communicator of their own (UH_SYNCBN_OWN_GROUP=1: two communicators issuing
+    collectives from one process, the bucket all-reduces from the side stream's events).  Every collective is the identity; the
+    statistics take the merge path (finalize -> gather -> finalize), so the parameters agree with the plain run to round-off."""
+    import unet_amd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unet_amd.UNet_S(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+    st = unet_amd.TrainStepper(model, lr=1e-4, amp=False, wgrad_stream=True)
+    im, mk = unet_amd.ellipse_batch(4, 96, seed=3)
+    for _ in range(3):
+        t = st.step(im.to(dev), mk.to(dev))
+    torch.cuda.synchronize()
+    ref_p, ref_loss = st.optimizer.flat_p.cpu(), float(t["loss"])
+    st.close()
+    (_, _, p, loss), = _spawn(_rccl_one_rank_syncbn_worker, own_group, world=1)
+    # (RMSprop's first steps are sign-like: lr * g / sqrt(0.01 g^2) -- a last-bit difference in a near-zero gradient moves that
+    # parameter by 2 * 10 * lr, so three steps agree to ~1e-3 of the parameter norm, not to round-off)
+    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss), (loss, ref_loss)
+    d = (torch.from_numpy(p) - ref_p).norm() / ref_p.norm()
+    assert d < 2e-3, d
+
+
 # ------------------------------------------------------------------------------------------ full-width bf16 under SyncBN
 def _fullwidth_syncbn_worker(rank, world, port, q):
     try:

@@ -393,22 +393,58 @@ def test_nan_loss_raises_and_leaves_parameters_untouched():
 
 
 def test_dice_after_training_matches_oracle():
-    """"Dice vs ref" (BASELINE metric): 200 train steps (lr 1e-4, where the curve has reached its plateau: RMSprop's
-    sign-like steps make the path there chaotic, the plateau is not) on synthetic ellipse batches, then evaluate.py's
-    Dice on a held-out batch -- HIP fp32 / bf16 vs the CPU oracle on the same data from the same initial weights."""
+    """"Dice vs ref" (BASELINE metric), like for like: 200 (+ 25 + 25) train steps (lr 1e-4) on synthetic ellipse batches from the
+    SAME five initialisations by the CPU oracle and by the HIP path (fp32, bf16), then evaluate.py's Dice on a held-out batch.
+    The recipe itself is chaotic on this tiny problem (the oracle slides from 0.92 to 0.74 on one of the five initialisations,
+    profiles/r04_dice_chaos_oracle.txt), so distributions are compared, not single runs: medians within 0.02, and no HIP run
+    further below the oracle's worst run than 0.15 -- both on the per-run mean over the 200 / 225 / 250-step checkpoints, where a
+    dip at one checkpoint weighs a third; the medians at step 200 itself are held too."""
     import bench
     r = bench.dice_vs_ref()
     _REPORT.append(f"dice_vs_ref {r}")
-    assert r["ref_cpu_fp32"] > 0.9, r                      # the task is learned
-    # HIP figures are medians over five initialisations: the path to the plateau is chaotic and single trajectories dip and
-    # recover (bench.dice_vs_ref quotes scratch/dice_chaos3.py: 0.77-0.85 at step 200 on two of twelve runs that read 0.94-0.98
-    # fifty steps later), so the median is held to the oracle and a single run only to "has learned the task"
-    assert abs(r["hip_fp32"] - r["ref_cpu_fp32"]) < 0.02, r
-    assert abs(r["hip_bf16"] - r["ref_cpu_fp32"]) < 0.03, r
-    # (a single checkpoint of a single run has been seen as low as 0.60 in the middle of a dip -- UH_FUSE_BNSUM=0, seed 4, bf16 --
-    # and back at 0.94+ fifty steps later: only "did not diverge" is asked of the worst run)
-    assert min(r["hip_fp32_runs"] + r["hip_bf16_runs"]) > 0.5, r
-    assert sum(1 for d in r["hip_fp32_runs"] + r["hip_bf16_runs"] if d > 0.95) >= 6, r
+    assert r["ref_cpu_fp32"] > 0.9 and r["ref_cpu_fp32_avg"] > 0.9, r                      # the task is learned
+    for name in ("hip_fp32", "hip_bf16"):
+        assert abs(r[name + "_avg"] - r["ref_cpu_fp32_avg"]) < 0.02, (name, r)
+        assert abs(r[name] - r["ref_cpu_fp32"]) < 0.02, (name, r)
+        assert min(r[name + "_avg_runs"]) >= min(r["ref_cpu_fp32_avg_runs"]) - 0.15, (name, r)
+
+
+@pytest.mark.parametrize("B,H,W,scale,w_b", [
+    (2, 64, 64, 1.0, 0.25),        # edge band covers the image (2 * 51 >= 64): interior empty; raw logits used as probabilities
+    (2, 160, 144, 1.0, 0.25),      # interior and edge regions, no sigmoid
+    (3, 130, 171, 8.0, 0.25),      # |logit| > 10 somewhere: the sigmoid branch of boundary_loss.py:28
+    (8, 512, 512, 1.5, 0.25),      # the benchmarked extent (1024 partial rows)
+    (2, 96, 96, 1.0, 0.0),         # no boundary term
+])
+def test_fused_binary_loss_is_bit_identical_to_the_separate_kernels(B, H, W, scale, w_b):
+    """uh_seg_loss_binary_fused (three launches) against uh_bce_dice_sums + uh_boundary_loss_mask + uh_seg_loss_binary_finish
+    (six): every loss term, the sums kept for the backward pass, the gradient of the logits and the NaN flag."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    logits = (torch.randn(B, H, W, generator=g) * scale).to(dev)
+    mask = torch.randint(0, 3, (B, H, W), generator=g).to(dev)
+    res = []
+    default = ops.FUSE_LOSS
+    try:
+        for fuse in (False, True):
+            ops.FUSE_LOSS = fuse
+            lg = logits.clone().requires_grad_(True)
+            total, bce, dice, bnd, nan_flag = ops.SegLossBinaryFn.apply(lg, mask, 2, w_b, 51, 15.0, None, 1)
+            assert (nan_flag is not None) == fuse
+            total.backward()
+            res.append((total.detach().clone(), bce.clone(), dice.clone(), bnd.clone(), lg.grad.clone(), nan_flag))
+    finally:
+        ops.FUSE_LOSS = default
+    torch.cuda.synchronize()
+    for a, b, name in zip(res[0][:5], res[1][:5], ("total", "bce", "dice", "boundary", "dlogits")):
+        assert torch.equal(a, b), (name, a, b)
+    assert float(res[1][5]) == 0.0
+    # a NaN logit raises the flag (and nothing else changes shape)
+    bad = logits.clone()
+    bad[0, 3, 5] = float("nan")
+    out = ops.SegLossBinaryFn.apply(bad, mask, 2, w_b, 51, 15.0, None, 1)
+    assert float(out[4]) == 1.0 and bool(torch.isnan(out[0]))
 
 
 def test_cc_loss_option_adds_value_only():

@@ -8,6 +8,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_pre_build():
+    """The PRE instantiations are a measured net loss and live behind a build flag: the default library
+    answers uh_conv3x3_pre_ok with 0 and refuses the two entry points.  Build and select the flagged library with
+        UH_BUILD_PRE=1 python unet-medical-image-contour-segmentation_amd/build.py
+        UH_LIB_PATH=$PWD/unet-medical-image-contour-segmentation_amd/libunet_hip_pre.so python -m pytest tests/test_gpu_pre_fusion.py -m gpu"""
+    from unet_amd._lib import LIB, UH_BF16
+    if not LIB.query("uh_conv3x3_pre_ok", 2, 64, 64, 128, 256, 128, 256, UH_BF16):
+        pytest.skip("this library was built without UH_BUILD_PRE=1")
+
+
 def _dev():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU")

@@ -11,14 +11,20 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
-LIB_PATH = os.path.join(PKG_DIR, "libunet_hip.so")
-OBJ_DIR = os.path.join(CSRC, "build")
+# UH_BUILD_PRE=1: a second library (own object directory) that also carries the consumer-side BatchNorm + ReLU instantiations
+# of the conv kernels; point the binding at it with UH_LIB_PATH (tests/test_gpu_pre_fusion.py, A/B runs)
+BUILD_PRE = os.environ.get("UH_BUILD_PRE") == "1"
+LIB_PATH = os.path.join(PKG_DIR, "libunet_hip_pre.so" if BUILD_PRE else "libunet_hip.so")
+OBJ_DIR = os.path.join(CSRC, "build_pre" if BUILD_PRE else "build")
 
 SOURCES = ["uh_error.hip", "conv3x3.hip", "bn.hip", "bn_fused.hip", "pool_up.hip", "convt_1x1.hip", "convt_mfma.hip", "loss.hip", "optim.hip", "cc_loss.hip", "infer.hip", "post_process.hip", "data_prep.hip", "stem_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # sources whose kernels carry hand-counted waits around inline-asm loads: their device ISA is kept (-save-temps) and
 # linted after every compile (isa_lint.py: no spill inside the MFMA region, no touch of an in-flight destination)
+# UH_BUILD_PRE=1 also compiles the consumer-side BatchNorm + ReLU instantiations of the conv kernels (uh_conv3x3_fwd_pre /
+# uh_conv3x3_wgrad_pre: built, measured, a net loss -- DESIGN.md section 3); the default library carries stubs that fail loudly.
+EXTRA_DEFINES = ["-DUH_BUILD_PRE=1"] if BUILD_PRE else []
 LINTED = {"conv3x3.hip": "conv3x3-hip-amdgcn-amd-amdhsa-gfx950.s"}
 
 
@@ -37,19 +43,33 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile what is stale, lint the hand-scheduled kernels that were recompiled, link.  Serialised across processes by a
+    file lock: every rank of a multi-process launch may call this, one of them builds, the others find everything fresh."""
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "unet_hip.h"))
     hipcc = _hipcc()
     jobs = []
     objs = []
+    rebuilt = set()
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             extra = ["-save-temps=obj"] if src in LINTED else []
-            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_DEFINES + extra + ["-c", s, "-o", o])
+            rebuilt.add(src)
 
     def run(cmd):
         if verbose:
@@ -61,22 +81,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    lint_isa(verbose)
+    # the lint reads (and prunes) the -save-temps by-products of THIS call's compile; objects that were not rebuilt were
+    # linted when they were (their report is kept beside them)
+    lint_isa(verbose, only={src for src in LINTED if src in rebuilt or
+                            not os.path.exists(os.path.join(OBJ_DIR, src.replace(".hip", ".isa_lint.json")))})
     if force or jobs or _stale(LIB_PATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 
-def lint_isa(verbose: bool = False) -> None:
-    """Check the ISA of the hand-scheduled kernels (see isa_lint.py); raises on a violation.  Runs on every build_library
-    call for which the ISA file exists (it is written next to the objects by the compile above)."""
+def lint_isa(verbose: bool = False, only=None) -> None:
+    """Check the ISA of the hand-scheduled kernels (see isa_lint.py); raises on a violation.  `only`: the sources to lint
+    (build_library passes the ones it has just recompiled); None = every linted source whose ISA file exists."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_uh_isa_lint", os.path.join(PKG_DIR, "isa_lint.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
     for src, isa in LINTED.items():
         path = os.path.join(OBJ_DIR, isa)
-        if not os.path.exists(path):
+        if (only is not None and src not in only) or not os.path.exists(path):
             continue                      # prebuilt objects without temps (the GPU box uses the shipped .so)
         errs, report = lint.lint_asm(open(path).read())
         stem = src.replace(".hip", "")
@@ -88,8 +111,14 @@ def lint_isa(verbose: bool = False) -> None:
             json.dump({"rocm": lint.rocm_version(), "validated_rocm": lint.VALIDATED_ROCM, "kernels": report,
                        "violations": errs}, f, indent=1)
         if lint.rocm_version() != lint.VALIDATED_ROCM:
-            print(f"WARNING: {src} was validated on ROCm {lint.VALIDATED_ROCM}, this is {lint.rocm_version()}: the hand-counted "
-                  "waits depend on hipcc's instruction selection -- run the parity tests before trusting this build", flush=True)
+            # the hand-counted s_waitcnt schedule depends on hipcc's instruction selection: another toolchain must be opted
+            # into explicitly (and the parity tests run) before its build of these kernels is linked
+            msg = (f"{src} was validated on ROCm {lint.VALIDATED_ROCM}, this is {lint.rocm_version()}: the hand-counted waits depend "
+                   "on hipcc's instruction selection")
+            if os.environ.get("UH_ALLOW_UNVALIDATED_ROCM") != "1":
+                os.remove(os.path.join(OBJ_DIR, src.replace(".hip", ".o")))
+                raise RuntimeError(msg + " -- set UH_ALLOW_UNVALIDATED_ROCM=1 to build anyway, then run the GPU parity tests")
+            print("WARNING: " + msg + " (UH_ALLOW_UNVALIDATED_ROCM=1): run the parity tests before trusting this build", flush=True)
         if errs:
             os.remove(os.path.join(OBJ_DIR, src.replace(".hip", ".o")))       # never link a build that failed the lint
             raise RuntimeError("ISA lint failed for " + src + ":\n  " + "\n  ".join(errs))

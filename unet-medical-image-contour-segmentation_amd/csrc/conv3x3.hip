@@ -555,6 +555,9 @@ __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }
 // are formed in this kernel's epilogue from the accumulators (rounded to bf16 as stored) and one read of q, like the forward's
 // statistics: one partial row per workgroup, [row][2][Cout] -- the layout uh_bn_bwd_finalize / uh_bn_relu_bwd_apply take.  The
 // uh_bn_relu_bwd_reduce pass (a read of dz and of q) is not launched for that layer.
+#ifndef UH_BUILD_PRE
+#define UH_BUILD_PRE 0        // build.py: UH_BUILD_PRE=1 compiles the PRE instantiations (A/B and tests/test_gpu_pre_fusion.py)
+#endif
 constexpr int PRE_MAX_C = 512;
 template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false, bool BSUM = false>
 __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
@@ -1841,6 +1844,10 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
             if (split && wfrag) { uh_set_error("conv3x3_fwd: bf16x3 filters are KRSC packs"); return UH_EINVAL; }
             if (narrow && wfrag) { uh_set_error("conv3x3_fwd: narrow-tensor calls take KRSC packs"); return UH_EINVAL; }
             if (pre) {
+#if !UH_BUILD_PRE
+                uh_set_error("conv3x3_fwd: the consumer-side BatchNorm+ReLU instantiations are not in this build (UH_BUILD_PRE=1); uh_conv3x3_pre_ok says so");
+                return UH_EINVAL;
+#else
                 if constexpr (ES == 2) {
                     if (split || narrow || C0 > PRE_MAX_C) { uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input needs a plain bf16 call with at most %d channels in source 0; ask uh_conv3x3_pre_ok first", PRE_MAX_C); return UH_EINVAL; }
                     const int wf = wfrag ? 1 : 0;
@@ -1864,6 +1871,7 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                     uh_set_error("conv3x3_fwd: the fused BatchNorm+ReLU input is a bf16 path; ask uh_conv3x3_pre_ok first");
                     return UH_EINVAL;
                 }
+#endif
             }
             if (bsum) {
                 if constexpr (ES == 2) {
@@ -2023,6 +2031,9 @@ extern "C" int uh_conv3x3_wfrag_ok(int B, int H, int W, int C0, int C1, int Cout
 // activation dtype exactly as uh_bn_relu_apply stores it -- the activation itself is never written.  bf16, single source of
 // <= 512 channels, LDS-DMA MFMA kernel only: uh_conv3x3_pre_ok says whether a call qualifies (else run uh_bn_relu_apply).
 extern "C" int uh_conv3x3_pre_ok(int B, int H, int W, int C0, int Cout, int ld0, int ldy, int dt) {
+#if !UH_BUILD_PRE
+    return 0;            // the default library does not carry the PRE instantiations (measured a net loss: DESIGN.md section 3)
+#endif
     if (dt != UH_BF16 || C0 > PRE_MAX_C) return 0;
     if (C0 % 64 || Cout % 64) return 0;                  // (backward-weights of the same layer works on 64-channel slabs)
     return uh_conv3x3_wfrag_ok(B, H, W, C0, 0, Cout, ld0, 0, ldy, dt);
@@ -2652,6 +2663,87 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     // The LDS-DMA is issued through inline asm (uh_dma16): the compiler does not see it, so it does not drain it in front
     // of the tile's first ds_read (which it does for the builtin -- the DMA of tile t+1 then overlapped nothing); it is
     // waited for by hand at the END of tile t, behind its 72 MFMAs per wave.
+    auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
+        s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + lo));
+        s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + hi));
+        s16x8 both = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        return __builtin_bit_cast(bf16x8, both);
+    };
+#ifndef UH_WGRAD_ROT
+#define UH_WGRAD_ROT 1      // 1: the tile loop is rotated (see below); 0: one barrier at the very end of a tile (round 3)
+#endif
+#if UH_WGRAD_M16 && UH_WGRAD_ROT
+    // ROTATED tile loop.  A tile = six x row pairs a (fragments of pair a + 1 are fetched while pair a is multiplied; dy pair
+    // p = a - r meets tap row r); the last LDS reads of a tile are those of pair 5, requested in front of pair 4's MFMAs.  The
+    // end-of-tile fence (next tile's DMA landed, everyone done READING this buffer) therefore sits in front of pair 5's twelve
+    // MFMAs, not behind them, and what used to open the next tile -- its first sixteen transposed reads -- is requested between
+    // the fence and those twelve MFMAs: when the barrier releases the workgroup, every SIMD has two waves with matrix work in
+    // hand instead of two waves waiting for LDS
+    // (profiles/r03_wgrad_phase_stamps.txt: the pipe was busy 0.67 of the tile loop; the start-of-tile reads of eight waves
+    // alone are ~500 LDS cycles).  Fragments of the next tile cross the loop back edge in dfr[0] / xfr[0].
+    bf16x8 dfr[4][2];
+    bf16x8 xfr[6][3][2];
+    auto ld_x = [&](const unsigned char* xs_, int a) {
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                xfr[a][sft][hh] = tr_pair(xs_ + a * (HALO_W * PB) + hh * 32, x_lo[sft], x_hi[sft]);
+    };
+    auto ld_d = [&](const unsigned char* ds_, int pr) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dfr[pr][h] = tr_pair(ds_ + pr * (TILE * DPB) + h * 32, d_lo, d_hi);
+    };
+    auto mma_pair = [&](int a) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int pr = a - r;
+            if (pr >= 0 && pr < 4) {
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+                            acc[r * 3 + sft][h][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[pr][h], xfr[a][sft][hh],
+                                                                                             acc[r * 3 + sft][h][hh], 0, 0, 0);
+            }
+        }
+    };
+    if (t_begin < t_end) issue(t_begin, 0);
+    tile_fence(t_begin, 0, t_begin < t_end);
+    ld_d(lds + XBYTES, 0);
+    ld_x(lds, 0);
+    int bufi = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+        const unsigned char* xs = lds + bufi * STAGE;
+        const unsigned char* ds = xs + XBYTES;
+        // the next tile's DMA, into the buffer the last fence released (behind this tile's first fragment reads, which were
+        // issued in front of pair 5 of the previous tile; issuing it there as well -- with pair 5's fragments still live --
+        // spilled ~30 registers into the MFMA stream)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            ld_x(xs, a + 1);
+            if (a + 1 < 4) ld_d(ds, a + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_pair(a);
+        }
+        // every LDS read of this tile has been issued (pair 5's in front of pair 4's MFMAs)
+        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
+        {
+            // (unconditional: behind the last tile these sixteen reads fetch stale LDS contents nobody uses -- a branch here
+            // makes the fragments phi nodes of the loop and costs ~20 spilled registers around the fence)
+            const unsigned char* xn = lds + (bufi ^ 1) * STAGE;
+            ld_d(xn + XBYTES, 0);
+            ld_x(xn, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair(5);
+    }
+#else
     if (t_begin < t_end) issue(t_begin, 0);
     tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
@@ -2662,12 +2754,6 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 #endif
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
-        auto tr_pair = [&](const unsigned char* row, int lo, int hi) -> bf16x8 {
-            s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + lo));
-            s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(row + hi));
-            s16x8 both = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            return __builtin_bit_cast(bf16x8, both);
-        };
 #if UH_WGRAD_M16
         // fully unrolled over the six x row pairs (a, a + 4): the fragments of pair a + 1 are fetched while pair a is
         // multiplied; dy pair p = a - r meets tap row r
@@ -2740,6 +2826,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 #endif
         tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
     }
+#endif
 
     float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
 #if UH_WGRAD_M16
@@ -3122,6 +3209,12 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         uh_set_error("uh_conv3x3_wgrad: bf16x3 needs an MFMA-aligned shape (channel counts multiples of 64, 16-byte strides)");
         return UH_EINVAL;
     }
+#if !UH_BUILD_PRE
+    if (pre) {
+        uh_set_error("uh_conv3x3_wgrad_pre: the consumer-side BatchNorm+ReLU instantiations are not in this build (UH_BUILD_PRE=1); uh_conv3x3_pre_ok says so");
+        return UH_EINVAL;
+    }
+#endif
     if (pre && !(ES == 2 && p.kind == 0 && dma && !narrow && !split)) {
         uh_set_error("uh_conv3x3_wgrad_pre: needs the bf16 LDS-DMA kernel (64-aligned channels, tensors below 2 GiB); ask uh_conv3x3_pre_ok first");
         return UH_EINVAL;
@@ -3145,6 +3238,7 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             if (dma) {
                 // byte extents of the (sliced) source views as seen from their base pointers
                 unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
+#if UH_BUILD_PRE
                 if (pre && p.nwr == 4)
                     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
                                        lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
@@ -3153,7 +3247,9 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
                     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 2, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
                                        lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
                                        C0v, C1v, Coutv, pre_scale, pre_shift);
-                else if (p.nwr == 4)
+                else
+#endif
+                if (p.nwr == 4)
                     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
                                        lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
                                        C0v, C1v, Coutv);

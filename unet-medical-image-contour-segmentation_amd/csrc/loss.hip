@@ -361,14 +361,16 @@ __global__ __launch_bounds__(256) void boundary_minmax_kernel(const float* __res
 __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __restrict__ pred, int64_t pstride, int64_t bstride,
                                                              const float* __restrict__ target, const int64_t* __restrict__ mask,
                                                              int mask_div, int B, BRegion g,
-                                                             const float* __restrict__ mm, int nmm,
+                                                             const float* __restrict__ mm, int nmm, int mm_stride,
                                                              float* __restrict__ partials) {
     // global min / max of the prediction from the <= 512 partial pairs, by the whole block (one thread walking them was
     // 512 dependent-latency loads in every block: 45 of this kernel's 56 us)
     __shared__ float s_mn[4], s_mx[4];
     {
         float mn = INFINITY, mx = -INFINITY;
-        for (int k = threadIdx.x; k < nmm; k += 256) { mn = fminf(mn, mm[2 * k]); mx = fmaxf(mx, mm[2 * k + 1]); }
+        // (pair k at mm[k * mm_stride], mm[k * mm_stride + 1]: packed pairs from boundary_minmax_kernel, or columns 4 / 5 of
+        // the fused pass's partial rows)
+        for (int k = threadIdx.x; k < nmm; k += 256) { mn = fminf(mn, mm[(int64_t)k * mm_stride]); mx = fmaxf(mx, mm[(int64_t)k * mm_stride + 1]); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
         if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
@@ -475,7 +477,7 @@ static int boundary_loss_impl(const float* pred, int64_t pstride, int64_t bstrid
     hipLaunchKernelGGL(boundary_minmax_kernel, dim3(nmm), dim3(256), 0, st, pred, pstride, n, H * W, bstride, mmbuf);
     UH_CHECK_LAUNCH("boundary_minmax_kernel");
     hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, mask, mask_div, B, g,
-                       (const float*)mmbuf, nmm, partials);
+                       (const float*)mmbuf, nmm, 2, partials);
     UH_CHECK_LAUNCH("boundary_count_kernel");
     hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, B, g, edge_weight,
                        smooth, out);
@@ -536,5 +538,112 @@ extern "C" int uh_seg_loss_multiclass_finish(const float* sums, int ncls, double
     hipLaunchKernelGGL(seg_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ncls, (float)(1.0 / n_mean),
                        boundary, w_boundary, out);
     UH_CHECK_LAUNCH("seg_loss_finish_kernel");
+    return UH_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ train.py:119-134 in three launches
+// The single-process binary loss (BCE mean + Dice + w * boundary_loss) used to be six launches plus the torch glue around
+// them (isnan, two fills, two copies): every one of them a 5-10 us step on the critical path between the forward and the
+// backward pass.  Here: ONE pass over the logits forms the BCE / Dice partial sums AND the prediction's min / max (the
+// sigmoid decision of boundary_loss.py:28), the boundary counts follow, and one finishing block writes the four sums the
+// backward pass needs, the four loss terms and the NaN flag of train.py:149.  Arithmetic, block counts and reduction orders
+// are those of uh_bce_dice_sums / uh_boundary_loss_mask / uh_seg_loss_binary_finish: the results are bit-identical.
+__global__ __launch_bounds__(256) void bce_dice_mm_sums_kernel(const float* __restrict__ logits, const int64_t* __restrict__ mask,
+                                                               int mask_div, int64_t n, float* __restrict__ partials) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float x = logits[i];
+        float t = (float)(mask[i] / mask_div);
+        float e = expf(-fabsf(x));
+        float sp = log1pf(e);
+        float s = (x >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+        v[0] += fmaxf(x, 0.f) - x * t + sp;
+        v[1] += s * t;
+        v[2] += s;
+        v[3] += t;
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+    }
+    __shared__ float smn[4], smx[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    float* row = partials + (int64_t)blockIdx.x * LOSS_ROW;
+    block_reduce_store<4>(v, row);                        // (its barrier also covers smn / smx)
+    if (threadIdx.x == 0) {
+        row[4] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        row[5] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_loss_fused_finish_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                                    int nblk, int B, BRegion g, float edge_weight, float smooth,
+                                                                    float w_boundary, float inv_n, float* __restrict__ sums,
+                                                                    float* __restrict__ out) {
+    __shared__ double red[256];
+    float fs[4];
+    for (int k = 0; k < 4; ++k) fs[k] = (float)column_sum_256(pa, nblk, k, red);
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (pb)
+        for (int k = 0; k < 6; ++k) s[k] = column_sum_256(pb, nblk, k, red);
+    if (threadIdx.x != 0) return;
+    float bl = 0.f;
+    if (pb) {
+        double n_int = 0.0, n_edge = 0.0;
+        const double tot = (double)g.H * g.W;
+        if (g.ew == 0) { n_int = tot; n_edge = 0.0; }
+        else if (g.interior_empty) { n_int = 0.0; n_edge = tot; }
+        else { n_int = (double)(g.H - 2 * g.ew) * (g.W - 2 * g.ew); n_edge = tot - n_int; }
+        n_int *= B; n_edge *= B;
+        const float normal = boundary_region_loss(s[0], s[1], s[2], n_int, smooth);
+        const float edge = boundary_region_loss(s[3], s[4], s[5], n_edge, smooth);
+        bl = (normal + edge_weight * edge) / (1.f + edge_weight);     // boundary_loss.py:44
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sums[k] = fs[k];
+    const float eps = 1e-6f;
+    const float inter = 2.f * fs[1];
+    float S = fs[2] + fs[3];
+    if (S == 0.f) S = inter;                                          // dice_score.py:16
+    const float dice_loss = 1.f - (inter + eps) / (S + eps);
+    const float ce = fs[0] * inv_n;
+    const float total = ce + dice_loss + w_boundary * bl;
+    out[0] = total;
+    out[1] = ce;
+    out[2] = dice_loss;
+    out[3] = bl;
+    out[4] = (total != total) ? 1.f : 0.f;                            // train.py:149 `torch.isnan(loss)`
+}
+
+extern "C" size_t uh_seg_loss_fused_ws_bytes(void) { return (size_t)2 * LOSS_MAXBLK * LOSS_ROW * sizeof(float); }
+
+extern "C" int uh_seg_loss_binary_fused(const float* logits, const int64_t* mask, int mask_div, int B, int H, int W,
+                                        int edge_width, float edge_weight, float smooth, float w_boundary, double n_mean,
+                                        float* sums, float* out, void* ws, size_t ws_bytes, uh_stream stream) {
+    UH_REQUIRE(logits && mask && sums && out && ws, "uh_seg_loss_binary_fused: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && mask_div >= 1 && edge_width >= 0 && n_mean > 0, "uh_seg_loss_binary_fused: bad args");
+    UH_REQUIRE(ws_bytes >= uh_seg_loss_fused_ws_bytes(), "uh_seg_loss_binary_fused: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * W;
+    const int nblk = loss_nblk(n);
+    float* pa = (float*)ws;
+    float* pb = pa + (size_t)LOSS_MAXBLK * LOSS_ROW;
+    BRegion g;
+    g.H = H; g.W = W; g.ew = edge_width;
+    g.interior_empty = (edge_width > 0) && (2 * edge_width >= H || 2 * edge_width >= W);
+    hipLaunchKernelGGL(bce_dice_mm_sums_kernel, dim3(nblk), dim3(256), 0, st, logits, mask, mask_div, n, pa);
+    UH_CHECK_LAUNCH("bce_dice_mm_sums_kernel");
+    const bool with_boundary = w_boundary != 0.f;
+    if (with_boundary) {
+        hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, logits, (int64_t)1, (int64_t)H * W, (const float*)nullptr,
+                           mask, mask_div, B, g, (const float*)(pa + 4), nblk, LOSS_ROW, pb);
+        UH_CHECK_LAUNCH("boundary_count_kernel");
+    }
+    hipLaunchKernelGGL(seg_loss_fused_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)pa,
+                       with_boundary ? (const float*)pb : (const float*)nullptr, nblk, B, g, edge_weight, smooth, w_boundary,
+                       (float)(1.0 / n_mean), sums, out);
+    UH_CHECK_LAUNCH("seg_loss_fused_finish_kernel");
     return UH_OK;
 }

@@ -512,6 +512,9 @@ def pre_fuse_ok(x0: torch.Tensor, mid: int, Cout: int) -> bool:
 # conv epilogue instead -- accumulators still in registers, one read of the raw output -- and the reduce pass is not launched
 # (8 of the 12 plain BatchNorm layers of the bilinear UNet).  UH_FUSE_BNSUM=0 turns it off.
 FUSE_BNSUM = os.environ.get("UH_FUSE_BNSUM", "1") != "0"
+# Layers (image height x channels of the tensor whose BatchNorm sums are formed, e.g. "32x512,512x64") that keep the separate
+# reduce pass although the fusion is on -- per-layer A/B runs (scratch/r4_bnsum_layers.sh) and the default exclusion list.
+BNSUM_OFF = {tuple(int(v) for v in k.split("x")) for k in os.environ.get("UH_BNSUM_OFF", "").split(",") if k}
 
 
 class BnSumLink:
@@ -519,11 +522,12 @@ class BnSumLink:
     output and BatchNorm coefficients in forward; the second layer's backward leaves the partial sums (and the gradient tensor
     they belong to); the first layer's backward uses them if the gradient it receives IS that tensor (autograd hands over the
     same storage when the activation had no other consumer), else it runs the reduce pass as before."""
-    __slots__ = ("y", "coef", "dz", "partials", "rows")
+    __slots__ = ("y", "coef", "dz", "dz_version", "partials", "rows")
 
     def __init__(self):
         self.y = self.coef = self.dz = self.partials = None
         self.rows = 0
+        self.dz_version = -1
 
 
 class ConvBnReluFn(Function):
@@ -606,13 +610,14 @@ class ConvBnReluFn(Function):
         ctx.training = training
         ctx.dims = (B, H, W, C0, C1, Cout)
         ctx.n_total = n_total
-        ctx.sync_bn = SYNC_BN if n_total != n else None
+        ctx.sync_bn = SYNC_BN                    # (None = per-rank statistics; a one-rank group under UH_DP_FORCE_SYNC still runs the collectives)
         ctx.tail = tail
         ctx.pre = pre_coef is not None
         ctx.bnsum_pub = ctx.bnsum_use = None
         if FUSE_BNSUM and x0.dtype == torch.bfloat16 and cdt == UH_BF16:
             if bnsum_pub is not None and tail == TAIL_NONE and not defer:
                 bnsum_pub.y, bnsum_pub.coef = y, coef
+                bnsum_pub.partials = bnsum_pub.dz = None      # (left over when a previous backward never reached this layer)
                 ctx.bnsum_pub = bnsum_pub
             if bnsum_use is not None and bnsum_use.y is not None and x1 is None and pre_coef is None:
                 ctx.bnsum_use = bnsum_use
@@ -730,8 +735,10 @@ class ConvBnReluFn(Function):
             link = ctx.bnsum_pub
             if link is not None:
                 # the sums came with the gradient (uh_conv3x3_dgrad_bnsum in the consumer's backward) -- if this IS that gradient
+                # (same storage, same extent, and not written since the sums were formed: a tensor hook or an in-place
+                # accumulation that edits the gradient keeps the storage and bumps the version counter)
                 if link.partials is not None and link.dz is not None and dz.data_ptr() == link.dz.data_ptr() and \
-                        dz.shape == link.dz.shape and dz.stride() == link.dz.stride():
+                        dz.shape == link.dz.shape and dz.stride() == link.dz.stride() and dz._version == link.dz_version:
                     partials, nblk = link.partials, link.rows
                 else:
                     link = None
@@ -769,7 +776,8 @@ class ConvBnReluFn(Function):
         if wd is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             use = ctx.bnsum_use
             rows = 0
-            if use is not None and use.y is not None and use.y.shape == (B, H, W, Cin) and use.y.is_contiguous():
+            if use is not None and use.y is not None and use.y.shape == (B, H, W, Cin) and use.y.is_contiguous() and \
+                    (H, Cin) not in BNSUM_OFF:
                 rows = LIB.query("uh_conv3x3_dgrad_bnsum_rows", B, H, W, Cout, Cin, Cout, Cin, Cin, ctx.cdt)
             if rows > 0:
                 # backward-data + the BatchNorm-backward sums of the layer in front (its reduce pass is not launched)
@@ -781,7 +789,7 @@ class ConvBnReluFn(Function):
                     LIB.call("uh_conv3x3_dgrad_bnsum", dy.data_ptr(), Cout, Cout, wd.data_ptr(), dx.data_ptr(), Cin, Cin,
                              use.y.data_ptr(), Cin, use.coef.data_ptr(), bsum.data_ptr(), B, H, W,
                              ctx.cdt | (UH_WFRAG if ctx.frag_d else 0), _stream())
-                use.partials, use.rows, use.dz = bsum, rows, dx
+                use.partials, use.rows, use.dz, use.dz_version = bsum, rows, dx, dx._version
             else:
                 dx, _, _ = conv3x3_fwd(dy, None, wd, Cin, False, ctx.cdt, ctx.frag_d)
             dx0 = dx[..., :C0] if ctx.needs_input_grad[0] else None
@@ -906,7 +914,7 @@ class StemConvBnReluFn(Function):
         ctx.bn_params = (gamma, beta)
         ctx.dims = (B, H, W, Cin, Cout)
         ctx.n_total = n_total
-        ctx.sync_bn = SYNC_BN if n_total != n else None
+        ctx.sync_bn = SYNC_BN                    # (None = per-rank statistics; a one-rank group under UH_DP_FORCE_SYNC still runs the collectives)
         return z
 
     @staticmethod
@@ -1083,7 +1091,7 @@ class ConvBnReluNarrowFn(Function):
         ctx.dims = (B, H, W, C0m, C1m, Cout, c0_true)
         ctx.cdt = cdt
         ctx.n_total = n_total
-        ctx.sync_bn = SYNC_BN if n_total != n else None
+        ctx.sync_bn = SYNC_BN                    # (None = per-rank statistics; a one-rank group under UH_DP_FORCE_SYNC still runs the collectives)
         return z
 
     @staticmethod
@@ -1382,10 +1390,27 @@ def boundary_loss_value(pred: torch.Tensor, pstride: int, bstride: int, target: 
     return out
 
 
+# Single-process binary loss as three launches (uh_seg_loss_binary_fused) instead of six + glue; False: the separate calls
+# (what data-parallel runs use anyway: their sums are all-reduced between the calls).  The two are bit-identical (tests).
+FUSE_LOSS = os.environ.get("UH_FUSE_LOSS", "1") != "0"
+_LOSS_WS = {}
+
+
+def _fused_loss_workspace(device) -> torch.Tensor:
+    """One workspace per device for the fused loss (its three launches run back to back on one stream; a second stream
+    using the loss concurrently on the same device is not a supported pattern of the train step)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        ws = _LOSS_WS[key] = torch.empty(LIB.query("uh_seg_loss_fused_ws_bytes"), dtype=torch.uint8, device=device)
+    return ws
+
+
 class SegLossBinaryFn(Function):
     """train.py:119-134 in one node: t = mask // mask_div; BCEWithLogits(mean) + dice_loss(sigmoid) +
-    w_boundary * boundary_loss(logits, t, 51, 15).  Returns [total, bce, dice, boundary]; only `total`
-    carries gradient (boundary_loss is constant w.r.t. the logits).
+    w_boundary * boundary_loss(logits, t, 51, 15).  Returns (total, bce, dice, boundary, nan_flag) as 0-dim tensors; only
+    `total` carries gradient (boundary_loss is constant w.r.t. the logits); nan_flag (float 0/1, or None when
+    the separate kernels ran) is train.py:149's isnan(loss) without a kernel of its own.
     `reduce_sums` (optional callable) all-reduces the 4 partial sums across data-parallel ranks so the
     Dice ratio and the BCE mean are those of the GLOBAL batch."""
 
@@ -1404,29 +1429,46 @@ class SegLossBinaryFn(Function):
             mk = mk.long()
         dev = lg.device
         sums = torch.empty(4, dtype=torch.float32, device=dev)
-        ws = loss_workspace(dev)
-        LIB.call("uh_bce_dice_sums", lg.data_ptr(), mk.data_ptr(), int(mask_div), None, n, sums.data_ptr(),
-                 ws.data_ptr(), ws.numel(), _stream())
-        if reduce_sums is not None:
-            reduce_sums(sums)
-        bl = None
-        if w_boundary != 0.0:
-            # boundary_loss(logits, (mask // mask_div).float(), 51, 15), train.py:134 -- the kernel divides the int64 mask itself
-            bl = torch.empty(1, dtype=torch.float32, device=dev)
-            LIB.call("uh_boundary_loss_mask", lg.data_ptr(), 1, H * W, mk.data_ptr(), int(mask_div), B, H, W, int(edge_width),
-                     float(edge_weight), 1e-6, bl.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
-        out = torch.empty(4, dtype=torch.float32, device=dev)
-        LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(round(n * world)), _p(bl), float(w_boundary),
-                 out.data_ptr(), _stream())
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        fused = FUSE_LOSS and reduce_sums is None
+        if fused:
+            ws = _fused_loss_workspace(dev)
+            LIB.call("uh_seg_loss_binary_fused", lg.data_ptr(), mk.data_ptr(), int(mask_div), B, H, W, int(edge_width),
+                     float(edge_weight), 1e-6, float(w_boundary), float(round(n * world)), sums.data_ptr(), out.data_ptr(),
+                     ws.data_ptr(), ws.numel(), _stream())
+        else:
+            ws = loss_workspace(dev)
+            LIB.call("uh_bce_dice_sums", lg.data_ptr(), mk.data_ptr(), int(mask_div), None, n, sums.data_ptr(),
+                     ws.data_ptr(), ws.numel(), _stream())
+            if reduce_sums is not None:
+                reduce_sums(sums)
+            bl = None
+            if w_boundary != 0.0:
+                # boundary_loss(logits, (mask // mask_div).float(), 51, 15), train.py:134 -- the kernel divides the int64 mask itself
+                bl = torch.empty(1, dtype=torch.float32, device=dev)
+                LIB.call("uh_boundary_loss_mask", lg.data_ptr(), 1, H * W, mk.data_ptr(), int(mask_div), B, H, W, int(edge_width),
+                         float(edge_weight), 1e-6, bl.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            LIB.call("uh_seg_loss_binary_finish", sums.data_ptr(), float(round(n * world)), _p(bl), float(w_boundary),
+                     out.data_ptr(), _stream())
         ctx.save_for_backward(lg, mk, sums)
         ctx.meta = (int(mask_div), n, world, logits.shape, logits.dtype)
-        return out
+        ctx.set_materialize_grads(False)
+        total, bce, dice, bnd = out[0], out[1], out[2], out[3]
+        nan_flag = out[4:5] if fused else None
+        ctx.mark_non_differentiable(bce, dice, bnd)
+        if nan_flag is not None:
+            ctx.mark_non_differentiable(nan_flag)
+        return total, bce, dice, bnd, nan_flag
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, g_total, *_unused):
         lg, mk, sums = ctx.saved_tensors
         mask_div, n, world, shape, dtype = ctx.meta
-        g0 = gout[0:1].contiguous().float()       # only the total carries gradient
+        if g_total is None:
+            return (None,) * 8
+        g0 = g_total.reshape(1)                   # only the total carries gradient
+        if g0.dtype != torch.float32 or not g0.is_contiguous():
+            g0 = g0.contiguous().float()
         dl = torch.empty_like(lg)
         LIB.call("uh_bce_dice_grad", lg.data_ptr(), mk.data_ptr(), mask_div, None, n, sums.data_ptr(),
                  float(round(n * world)), 1.0, 1.0, g0.data_ptr(), dl.data_ptr(), _stream())

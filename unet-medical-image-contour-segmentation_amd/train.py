@@ -12,6 +12,7 @@ works unchanged: the modules are ordinary nn.Modules.
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, Iterable, Optional
 
@@ -31,8 +32,11 @@ def seg_loss(masks_pred: torch.Tensor, true_masks: torch.Tensor, n_classes: int,
     if n_classes == 1:
         w_b = 0.25 if boundary_weight is None else boundary_weight          # train.py:134
         lg = masks_pred.squeeze(1)
-        out = ops.SegLossBinaryFn.apply(lg, true_masks, 2, w_b, 51, 15.0, reduce_sums, world)
-        return {"loss": out[0], "bce": out[1].detach(), "dice": out[2].detach(), "boundary": out[3].detach()}
+        total, bce, dice, bnd, nan_flag = ops.SegLossBinaryFn.apply(lg, true_masks, 2, w_b, 51, 15.0, reduce_sums, world)
+        terms = {"loss": total, "bce": bce, "dice": dice, "boundary": bnd}
+        if nan_flag is not None:
+            terms["nan_flag"] = nan_flag          # float 0 / 1 written by the loss's finishing block (train.py:149)
+        return terms
     w_b = 0.0 if boundary_weight is None else boundary_weight               # train.py:143-147 is commented out
     lg = masks_pred.permute(0, 2, 3, 1)
     out = ops.SegLossMulticlassFn.apply(lg, true_masks, w_b, 51, 7.0, reduce_sums, world)
@@ -80,6 +84,7 @@ class FusedRMSprop:
         self._closed = False
         # one backward per step: which slices of flat_g hold THIS step's gradient (reset by zero_grad / step)
         self._fresh = [False] * len(self.params)
+        self._stale_verified = None                  # data parallel: the fresh / stale pattern the ranks agreed on (first step)
         with torch.no_grad():
             for i, (p, (o, n)) in enumerate(zip(self.params, slices)):
                 if p.dtype != torch.float32:
@@ -172,6 +177,28 @@ class FusedRMSprop:
             self.sync.wait()
         self._fresh = [False] * len(self.params)
 
+    def _check_stale_pattern(self):
+        """Data parallel: "skip a parameter that got no gradient" is only what torch.optim + DDP do when EVERY rank skips it
+        (behind DDP's all-reduce .grad is non-None on every rank).  A parameter that is fresh on one rank and stale on another
+        would be updated on one replica only, silently.  The pattern is therefore compared across the ranks on the first
+        step (one tiny all-reduce + host read, once), and must not change afterwards (a purely local test, so no rank can
+        be left waiting at a collective the others skip).  U-Net uses every parameter on every step: this never fires there."""
+        pattern = tuple(self._fresh)
+        if self._stale_verified is None:
+            import torch.distributed as dist
+            bits = torch.tensor([1.0 if f else 0.0 for f in pattern], dtype=torch.float32, device=self.flat_g.device)
+            both = torch.stack([bits, -bits])
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.sync.group)     # max(bits), -min(bits)
+            if bool((both[0] != -both[1]).any().item()):
+                raise RuntimeError("FusedRMSprop (data parallel): a parameter received a gradient on some ranks and none on "
+                                   "others; the replicas would diverge (give every rank the same set of trainable / used "
+                                   "parameters)")
+            self._stale_verified = pattern
+        elif pattern != self._stale_verified:
+            raise RuntimeError("FusedRMSprop (data parallel): the set of parameters that receive gradients changed between "
+                               "steps; it was agreed across the ranks on the first step and cannot be re-checked without a "
+                               "blocking collective")
+
     @torch.no_grad()
     def step(self):
         if self._closed:
@@ -185,6 +212,8 @@ class FusedRMSprop:
         stale = [i for i, f in enumerate(self._fresh) if not f]
         if stale and len(stale) == len(self._fresh):
             raise RuntimeError("FusedRMSprop.step() without a backward pass since the last step / zero_grad")
+        if self.sync is not None:
+            self._check_stale_pattern()
         runs = [(0, self.total)]
         if stale:
             for i in stale:
@@ -255,6 +284,26 @@ def _is_dense(p: torch.Tensor) -> bool:
 
 
 # ----------------------------------------------------------------------------------- one step
+_ONES = {}
+_PINNED = {}
+
+
+def _one_like(loss: torch.Tensor) -> torch.Tensor:
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return t
+
+
+def _pinned_flag(device) -> torch.Tensor:
+    """A pinned float the NaN flag is copied into (one per device: it is read back before the next step writes it)."""
+    t = _PINNED.get(device)
+    if t is None:
+        t = _PINNED[device] = torch.zeros(1, dtype=torch.float32).pin_memory()
+    return t
+
+
 def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: torch.Tensor, *, amp: bool = True,
                gradient_clipping: float = 1.0, reduce_sums=None, world: int = 1, check_nan: bool = True,
                boundary_weight: Optional[float] = None, cc_loss: bool = False) -> Dict[str, torch.Tensor]:
@@ -278,26 +327,30 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
         terms["cc"] = torch.tensor(cc, device=masks_pred.device)
         terms["loss"] = terms["loss"] + cc
     loss = terms["loss"]
+    nan_flag = terms.pop("nan_flag", None)       # (not one of the reported terms)
     nan_host = nan_event = None
     if check_nan:
         # train.py:149-151 raises before backward().  Reading the flag right here would stall the host until the
         # forward has drained and leave the GPU idle while backward is being enqueued, so the flag travels to pinned
         # memory asynchronously and is read after backward has been ENQUEUED, still before the optimizer step: a NaN
         # loss raises the same error and never reaches the parameters.
-        nan_host = torch.empty(1, dtype=torch.bool, pin_memory=True)
-        flag = torch.isnan(loss.detach()).reshape(1)
+        flag = nan_flag
+        if flag is None or cc_loss:
+            flag = torch.isnan(loss.detach()).reshape(1).float()
         if reduce_sums is not None:
             # data parallel: boundary_loss (and so the loss value) is per rank; every rank must take the SAME decision, or
             # the ranks that continue hang at their next collective while one has raised
-            flag = reduce_sums(flag.float()) > 0
+            flag = reduce_sums(flag)
+        nan_host = _pinned_flag(loss.device)
         nan_host.copy_(flag, non_blocking=True)
         nan_event = torch.cuda.Event()
         nan_event.record()
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    # (the seed gradient is a cached constant: loss.backward() alone launches a fill kernel for it every step)
+    loss.backward(gradient=_one_like(loss))
     if nan_event is not None:
         nan_event.synchronize()
-        if bool(nan_host.item()):
+        if float(nan_host.item()) > 0:
             if isinstance(optimizer, FusedRMSprop):
                 optimizer.abort_step()
             raise RuntimeError("Fatal: NaN loss detected!")                                   # train.py:149-151
@@ -335,18 +388,47 @@ class TrainStepper:
         # sync_bn: BatchNorm statistics (forward) and their backward sums over the GLOBAL batch -> the data-parallel step
         # reproduces the single-process step on the concatenated batch (SURVEY.md 8e option 2); default = per-rank
         # statistics like stock DDP.  One all_gather (2C+1 floats) + one all_reduce (2C floats) per BatchNorm layer.
-        # Its collectives run on a process group of their OWN: on the gradient group they would queue, inside RCCL's one
-        # stream per communicator, behind bucket all-reduces that wait for side-stream backward-weights events -- and the
-        # critical-path BatchNorm backward would stall behind work it does not depend on.
+        # Its collectives run on the GRADIENT group by default.  UH_SYNCBN_OWN_GROUP=1 gives them a process group of their own
+        # (on the gradient group they queue, inside RCCL's one stream per communicator, behind bucket all-reduces; with the
+        # opt-in side stream for backward-weights those wait for side-stream events, and the critical-path BatchNorm backward
+        # would stall behind work it does not depend on).  Opt-in because two communicators issuing collectives concurrently
+        # from one process is the pattern RCCL deadlocks on when the ranks enqueue them in different orders, and no N > 1
+        # RCCL box has run it yet; because dist.new_group is a collective over the WHOLE default group (a stepper built on a
+        # sub-group must be constructed by every rank of the job); and because the extra communicator has to be destroyed
+        # (close()).  UH_DP_FORCE_SYNC=1 turns SyncBN on in a ONE-rank group too, so that both communicators are exercised
+        # against the real backend on a one-GPU box (tests/test_gpu_dp.py).
         self.sync_bn = None
-        if sync_bn and self.world > 1:
+        self.bn_group = None
+        if sync_bn and dpmod.sync_enabled(process_group):
             import torch.distributed as dist
-            ranks = dist.get_process_group_ranks(process_group) if process_group is not None else list(range(self.world))
-            self.bn_group = dist.new_group(ranks=ranks)       # collective: every rank of the group constructs its stepper
-            self.sync_bn = (self.bn_group, self.world)
+            group = process_group
+            if os.environ.get("UH_SYNCBN_OWN_GROUP") == "1":
+                ranks = dist.get_process_group_ranks(process_group) if process_group is not None else list(range(dist.get_world_size()))
+                self.bn_group = group = dist.new_group(ranks=ranks)
+            self.sync_bn = (group, self.world)
         self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
                                       gradient_clipping=gradient_clipping, process_group=process_group)
         self._pack = None
+
+    def close(self):
+        """Release what the stepper owns outside torch's garbage collection: the optimizer's hooks and, when SyncBN runs on
+        a process group of its own (UH_SYNCBN_OWN_GROUP=1), that communicator."""
+        opt = getattr(self, "optimizer", None)
+        if opt is not None:
+            opt.close()
+        grp, self.bn_group = getattr(self, "bn_group", None), None
+        if grp is not None:
+            import torch.distributed as dist
+            self.sync_bn = None
+            if dist.is_initialized():
+                dist.destroy_process_group(grp)
+
+    def __del__(self):
+        try:
+            if getattr(self, "bn_group", None) is not None:
+                self.close()
+        except Exception:
+            pass
 
     def step(self, images, true_masks, global_batch: Optional[int] = None):
         """One optimizer step (train.py:113-159).  `global_batch` (data parallel with sync_bn): the sum of the ranks' batch
