@@ -397,8 +397,14 @@ def main():
         ops.PROFILE.clear()
         ops.PROFILE_ON = rank == 0
         side, stepper.wgrad_stream = stepper.wgrad_stream, None      # time every kernel alone on the launch stream
-        run_step(im, mk)
-        torch.cuda.synchronize()
+        # every backward-weights launch is timed WITH its slab reduction, as in rounds 1-3 (the timed steps batch the eighteen
+        # reductions into one launch behind the backward pass, which would leave them out of the per-layer figures)
+        defer, ops.DEFER_SLABS = ops.DEFER_SLABS, False
+        try:
+            run_step(im, mk)
+            torch.cuda.synchronize()
+        finally:
+            ops.DEFER_SLABS = defer
         stepper.wgrad_stream = side
         ops.PROFILE_ON = False
         launches = [(n, f, e0.elapsed_time(e1) * 1e-3, t) for n, f, e0, e1, t in ops.PROFILE]

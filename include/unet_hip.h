@@ -134,6 +134,17 @@ size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt)
 int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
                      const void* x1, int C1, int ld1, float* dw_krsc, int Cout,
                      void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
+/* Backward-weights in two stages, the second deferred and batched.  uh_conv3x3_wgrad_partials = uh_conv3x3_wgrad without its
+ * closing reduction over the pixel splits: the partial results stay in `ws` (which must stay alive and untouched until the
+ * reduction has run) and desc[0..7] -- HOST memory -- receives { slabs, dw_krsc, n, nsplit, format, row, blocks, 0 }; desc[3] == 0
+ * means the shape took a path without slabs and dw_krsc is already final.  uh_slab_reduce_batched finishes any number of such
+ * layers in ONE launch: `table` is DEVICE memory holding the rows (8 int64 each) with [6] replaced by the row's first block
+ * (running sum of the block counts), total_blocks their sum.  Filter gradients only feed the optimizer (train.py:157-158), so
+ * the eighteen small reduce launches of a backward pass can wait until then.  Results are bit-identical to uh_conv3x3_wgrad. */
+int uh_conv3x3_wgrad_partials(const void* dy, int lddy, const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
+                              float* dw_krsc, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, int dt,
+                              int64_t* desc, uh_stream stream);
+int uh_slab_reduce_batched(const int64_t* table, int nrows, int64_t total_blocks, uh_stream stream);
 /* The BatchNorm + ReLU BETWEEN the two convs of a DoubleConv (unet_parts.py:16-17) applied by the CONSUMER conv's loader
  * (SURVEY.md section 7 step 6): x0 is the RAW output y_prev of the previous conv and the layer's input
  *     x = max(y_prev * pre_scale + pre_shift, 0)            (per channel of source 0, rounded to bf16 as uh_bn_relu_apply stores it)

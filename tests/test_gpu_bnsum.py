@@ -23,7 +23,8 @@ SHAPES = [
     (2, 64, 64, 256, 128),       # NBW = 1: too few tiles for the 128-channel slabs
     (1, 176, 160, 256, 256),     # NBW = 2 (128 accumulators), more tiles than workgroups per slab
     (2, 250, 131, 64, 128),      # NBW = 2, odd sizes: clamped rows and columns in the border tiles
-    (3, 16, 16, 512, 512),       # one-tile images, deep K
+    (3, 16, 16, 512, 512),       # one-tile images, deep K (K split inside the 8-wave workgroup, KS = 2)
+    (4, 32, 32, 512, 512),       # down4.3 at 4 images per GPU: KS = 2 over 16 tiles x 8 slabs
     (8, 128, 128, 256, 256),     # down2 of BASELINE config 2 at its benchmarked extent
 ]
 

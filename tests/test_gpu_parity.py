@@ -515,6 +515,36 @@ def test_graph_captured_step_matches_eager(ctor, bilinear, amp):
         assert torch.equal(model.state_dict()[k], v), k
 
 
+@pytest.mark.parametrize("amp,graphed", [(True, False), (False, False), (True, True)])
+def test_batched_slab_reduction_is_bit_identical_to_the_per_layer_launches(amp, graphed):
+    """ops.SlabBatch: the closing reductions of backward-weights wait for ONE launch behind the backward pass (channels_last
+    filters: the gradients go straight into the optimizer's flat buffer).  Same arithmetic, same order: parameters, clipped
+    gradients and loss are bit-identical to the step that reduces every layer at once -- eager and replayed from a graph."""
+    import unet_amd
+    from unet_amd import ops
+    dev = _dev()
+    im, mk = unet_amd.ellipse_batch(2, 96, seed=12)
+    res = []
+    default = ops.DEFER_SLABS
+    try:
+        for defer in (False, True):
+            ops.DEFER_SLABS = defer
+            torch.manual_seed(0)
+            model = unet_amd.UNet(1, 1, bilinear=True).to(memory_format=torch.channels_last).to(dev)
+            st = (unet_amd.GraphedTrainStepper if graphed else unet_amd.TrainStepper)(model, lr=1e-4, amp=amp)
+            for _ in range(3):
+                t = st.step(im.to(dev), mk.to(dev))
+            torch.cuda.synchronize()
+            if defer:
+                assert st._slabs._table is not None and st._slabs._table[1] == 17 and not st._slabs.rows     # 17 MFMA layers queued, flushed
+            res.append((float(t["loss"].detach()), st.optimizer.flat_p.clone(), st.optimizer.flat_g.clone()))
+            st.close()
+    finally:
+        ops.DEFER_SLABS = default
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_full_unet_step_fp32_bf16x3_vs_oracle():
     """fp32_mode='bf16x3' (3x3 forward / backward-data products on the bf16 matrix pipe, fp32 everywhere else) against the
     CPU oracle: logits and loss well inside the 1e-3 parity bar; gradients like the exact fp32 path (ill-conditioned, L2)."""

@@ -559,8 +559,17 @@ __device__ __forceinline__ int halo_swz(int hx) { return ((hx >> 2) & 1) << 1; }
 #define UH_BUILD_PRE 0        // build.py: UH_BUILD_PRE=1 compiles the PRE instantiations (A/B and tests/test_gpu_pre_fusion.py)
 #endif
 constexpr int PRE_MAX_C = 512;
-template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false, bool BSUM = false>
-__global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
+// KS = 2 (bf16, NBW = 1, exactly ONE tile per workgroup): the deep layers of a small batch -- 512 channels at 32 x 32 -- have
+// fewer (tile, channel slab) pairs than the chip has CUs and 16+ K-chunks per tile: one 4-wave workgroup per CU, i.e. ONE wave
+// per SIMD working through a serial chain of chunks with nothing to hide its LDS / MFMA latencies behind (40 us for 19 GFLOP
+// at batch 4).  With KS = 2 the workgroup has EIGHT waves: waves 0-3 contract the first half of the K-chunks, waves 4-7 the
+// second half (own halo double buffer each, same hand-counted pipeline), the two partial accumulator sets meet in LDS once
+// at the end (the halo buffers are free by then: nothing follows the only tile) and waves 0-3 run the epilogue unchanged --
+// two waves per SIMD, half the chain each.  Sums are added in a fixed order (first half + second half): deterministic.
+template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false, bool BSUM = false, int KS = 1>
+// (three workgroups per CU -- 168 registers -- for the 16-channel-per-wave form; its BSUM instantiation needs more than that for
+// the epilogue's batches and spilled 42 instructions per tile at 168: two per CU, like the other wide-register forms)
+__global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
     int B, int H, int W, int tilesX, int tilesY, unsigned x0_bytes, unsigned x1_bytes, unsigned y_bytes,
@@ -569,6 +578,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     const T* __restrict__ bs_y = nullptr, int bs_ld = 0, unsigned bs_bytes = 0, const float* __restrict__ bs_coef = nullptr) {
     static_assert(!PRE || (sizeof(T) == 2 && !SPLIT), "PRE is the bf16 training path");
     static_assert(!BSUM || (sizeof(T) == 2 && !SPLIT && !PRE), "BSUM is the bf16 backward-data path");
+    static_assert(KS == 1 || (KS == 2 && sizeof(T) == 2 && NBW == 1 && !SPLIT && !WRES && !PRE), "KS = 2 is a bf16 NBW = 1 form");
     if constexpr (BSUM) {
         // a plain single-source call (the host checks it): folding the second source, the narrow-tensor counts and the inference
         // epilogue away frees the scalar registers the extra arguments take -- the scalar file is full (the base kernel already
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
 #endif
     constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO2_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * HALO2_STRIDE];
     // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
     // S1 = sum (v - p), S2 = sum (v - p)^2 with p = one stored value of the channel (so that |mean - p| ~ std and the
     // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
@@ -601,9 +611,14 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     __shared__ __attribute__((aligned(16))) float bs_tab[BSUM ? 4 * BN : 4];            // BSUM: [scale | shift | mean | rstd][slot]
     float n_run = 0.f;
 
-    const int tid = threadIdx.x;
+    // KS = 2: `tid` / `wave` are the indices inside the thread's K-group (0 .. 255 / 0 .. 3): DMA slots, filter rows and
+    // channel ownership are per group; `grp` picks the group's half of the chunks and its own pair of halo buffers
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = wave_all & 3;
+    const int grp = KS == 2 ? (wave_all >> 2) : 0;
+    unsigned char* const lds = lds_all + grp * (2 * HALO2_STRIDE);
     const int lx = lane & 15, kg = lane >> 4;
     // XCD-aware block mapping (1-D grid of nlanes * nslab workgroups, nlanes % 8 == 0 or nslab == 1): blocks are dealt
     // round-robin to the 8 XCDs, so id % 8 labels the XCD; all channel slabs of one tile lane get the SAME label and
@@ -908,8 +923,11 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
     auto wsel = [&](WFrag (&wv)[3][NBW]) { return [&wv](int r, int n) -> const WFrag& { return wv[r][n]; }; };
     // WRES: the resident filter, [chunk][tap][n]
     WFrag wres[WRES ? 2 : 1][WRES ? 9 : 1][NBW];
+    // this thread's share of the K-chunks: all of them, or (KS = 2) its group's half
+    const int v_first = KS == 2 ? grp * (nchunk >> 1) : 0;
+    const int v_end = KS == 2 ? v_first + (nchunk >> 1) : nchunk;
     dma_tile(tile);
-    dma_chunk(chunk_of(0), 0, true);
+    dma_chunk(chunk_of(v_first), 0, true);
     if constexpr (WRES) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -921,7 +939,7 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
                     wfrag_async(wres[c][t][n], (int64_t)c * CK + n * wnb_stride + (int64_t)t * Cin, n, t, c);
                 }
     } else {
-        load_w(wA, chunk_of(0), 0);
+        load_w(wA, chunk_of(v_first), 0);
     }
     if constexpr (PRE) {
         // the coefficient table must be complete before the first rewrite: one extra barrier, once per kernel
@@ -936,10 +954,11 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
-    chunk_fence(chunk_of(0), 0, true);
+    chunk_fence(chunk_of(v_first), 0, true);
 
     for (; tile < ntile; tile += nlanes) {
-        const int next_tile = tile + nlanes;
+        if (KS == 2 && tile != tile_lane) break;     // (one tile per workgroup: the host sizes the grid that way)
+        const int next_tile = KS == 2 ? ntile : tile + nlanes;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -966,9 +985,9 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             }
         } else {
 #pragma unroll 1
-        for (int v = 0; v < nchunk; ++v, bufi ^= 1) {
+        for (int v = v_first; v < v_end; ++v, bufi ^= 1) {
             const int cur_c = chunk_of(v);
-            const int next_c = chunk_of((v + 1 < nchunk) ? v + 1 : 0);   // wraps to chunk 0 of the next tile
+            const int next_c = chunk_of((v + 1 < v_end) ? v + 1 : v_first);   // wraps to the first chunk of the next tile
             const unsigned char* buf = lds + bufi * HALO2_STRIDE;
             load_w(wB, cur_c, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -977,12 +996,12 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
             // the halo tile of what follows chunk v: the tile's next chunk, else chunk 0 of the workgroup's next tile, else
             // nothing (six out-of-range pieces keep the instruction count of the waits below)
             bool live_next = true;
-            if (v + 1 < nchunk) {
+            if (v + 1 < v_end) {
                 dma_chunk(chunk_of(v + 1), bufi ^ 1, true);
             } else {
                 live_next = next_tile < ntile;
                 if (live_next) dma_tile(next_tile);
-                dma_chunk(chunk_of(0), bufi ^ 1, live_next);
+                dma_chunk(chunk_of(v_first), bufi ^ 1, live_next);
             }
             UH_WAIT_VM(NWLOAD + NLOAD);               // WB landed (WC and the DMA stay in flight)
             mma_shift(buf, 1, wsel(wB));
@@ -994,6 +1013,24 @@ __global__ __launch_bounds__(256, ((NBW == 1 && !WRES) ? 3 : 2)) void conv3x3_fw
         }
         }
 
+        if constexpr (KS == 2) {
+            // The two halves of the contraction meet: the last chunk fence has drained every DMA and every wave is done reading
+            // (the host launches one tile per workgroup: no next tile was requested), so the four halo buffers are scratch now.
+            // Waves 4-7 park their accumulators lane-major (conflict-free 16-byte writes), waves 0-3 add them in a fixed order.
+            f32x4* scratch = reinterpret_cast<f32x4*>(lds_all);
+            if (grp == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) scratch[(i * NBW + n) * 256 + tid] = acc[i][n];
+            }
+            __syncthreads();
+            if (grp == 1) return;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) acc[i][n] += scratch[(i * NBW + n) * 256 + tid];
+        }
         // ---- epilogue: acc[i][n][j] = y[pixel (row i, col lx)][channel co_blk + ch(kg, n, j)]
         int t = tile;
         const int txt = t % tilesX; t /= tilesX;
@@ -1787,8 +1824,15 @@ static bool uh_no_wres() {
 
 // Which bf16 instantiation of conv3x3_fwd_mfma_v2 a plain call takes and how many tile lanes (= workgroups per channel slab =
 // statistics / partial rows written) it is launched with.  Mirrors the branches of conv3x3_fwd_dispatch below.
-struct FwdSel { int nbw; bool wres; int slabs; int gx; };
-static FwdSel fwd_select(int ntile, int Cin, int Cout, bool bf16_plain) {
+// K split inside the workgroup (KS = 2, see the kernel): bf16, 16 channels per wave, at most one (tile, 64-channel slab) pair
+// per CU and an even number (>= 8) of 32-channel K-chunks.  UH_NO_KSPLIT=1 turns it off (A/B runs).
+static bool fwd_ksplit_ok(int ntile, int Cin, int Cout) {
+    static const bool off = getenv("UH_NO_KSPLIT") != nullptr && getenv("UH_NO_KSPLIT")[0] == '1';
+    const int nchunk = Cin / 32;
+    return !off && Cin % 32 == 0 && Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) <= 256 && nchunk >= 8 && nchunk % 2 == 0;
+}
+struct FwdSel { int nbw; bool wres; int slabs; int gx; int ks; };
+static FwdSel fwd_select(int ntile, int Cin, int Cout, bool bf16_plain, bool bsum = false) {
     auto lanes_for = [&](int per_cu, int slabs) {
         int gx = (per_cu * 256 + slabs - 1) / slabs;
         gx = (gx + 7) & ~7;
@@ -1796,9 +1840,13 @@ static FwdSel fwd_select(int ntile, int Cin, int Cout, bool bf16_plain) {
         return gx;
     };
     FwdSel r;
+    r.ks = 1;
     if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) { r.nbw = 2; r.wres = false; r.slabs = Cout / 128; r.gx = lanes_for(2, r.slabs); }
     else if (bf16_plain && Cin == 64 && !uh_no_wres()) { r.nbw = 1; r.wres = true; r.slabs = Cout / 64; r.gx = lanes_for(2, r.slabs); }
-    else { r.nbw = 1; r.wres = false; r.slabs = Cout / 64; r.gx = lanes_for(3, r.slabs); }
+    else {
+        r.nbw = 1; r.wres = false; r.slabs = Cout / 64; r.gx = lanes_for(bsum ? 2 : 3, r.slabs);
+        if (bf16_plain && fwd_ksplit_ok(ntile, Cin, Cout)) { r.ks = 2; r.gx = ntile; }      // one tile per (8-wave) workgroup
+    }
     return r;
 }
 
@@ -1880,9 +1928,13 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                         uh_set_error("uh_conv3x3_dgrad_bnsum: needs a plain single-source bf16 call and a 16-byte aligned BatchNorm input below 2 GiB; ask uh_conv3x3_dgrad_bnsum_rows first");
                         return UH_EINVAL;
                     }
-                    const FwdSel sel = fwd_select(ntile, Cin, Cout, true);
+                    const FwdSel sel = fwd_select(ntile, Cin, Cout, true, true);
                     const int wf = wfrag ? 1 : 0, grid = sel.gx * sel.slabs;
-                    if (sel.nbw == 2)
+                    if (sel.ks == 2)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, false, false, true, 2>), dim3(grid), dim3(512), 0, st, x0, C0, ld0, x1, C1, ld1,
+                                           w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, nullptr, nullptr, C0v, C1v, Coutv, wf,
+                                           nullptr, nullptr, bs_y, bs_ld, (unsigned)bq, bs_coef);
+                    else if (sel.nbw == 2)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 2, false, false, false, true>), dim3(grid), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
                                            w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, nullptr, nullptr, C0v, C1v, Coutv, wf,
                                            nullptr, nullptr, bs_y, bs_ld, (unsigned)bq, bs_coef);
@@ -1922,6 +1974,11 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                     if constexpr (CAN_SPLIT)
                         hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, true>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1, C1, ld1,
                                            w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
+                } else if (ES == 2 && !narrow && fwd_ksplit_ok(ntile, Cin, Cout)) {
+                    // few tiles, long contraction: eight waves per workgroup, each half of them half of the K-chunks, one tile each
+                    if constexpr (ES == 2)
+                        hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1, false, false, false, false, 2>), dim3(ntile * slabs), dim3(512), 0, st, x0, C0, ld0, x1,
+                                           C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
                 } else
                     hipLaunchKernelGGL((conv3x3_fwd_mfma_v2<T, 1>), dim3(gx * slabs), dim3(256), 0, st, x0, C0, ld0, x1,
                                        C1, ld1, w, y, ldy, Cout, stats, B, H, W, tilesX, tilesY, (unsigned)b0, (unsigned)b1, (unsigned)by, ep_scale, ep_shift, C0v, C1v, Coutv, wfrag ? 1 : 0);
@@ -2066,7 +2123,7 @@ extern "C" int uh_conv3x3_dgrad_bnsum_rows(int B, int H, int W, int Cdy, int Cdx
     if (!uh_conv3x3_wfrag_ok(B, H, W, Cdy, 0, Cdx, lddy, 0, lddx, dt)) return 0;
     if (ldq != lddx) return 0;                 // q is addressed with the offsets of the tensor being written
     const int ntile = B * ((H + TILE - 1) / TILE) * ((W + TILE - 1) / TILE);
-    return fwd_select(ntile, Cdy, Cdx, true).gx;
+    return fwd_select(ntile, Cdy, Cdx, true, true).gx;
 }
 
 extern "C" int uh_conv3x3_dgrad_bnsum(const void* dy, int Cdy, int lddy, const void* w_dgrad, void* dx, int lddx, int Cdx,
@@ -2399,11 +2456,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
 }
 
 // out[i] = sum_k slabs[k][i]; block = 64 float4 columns x 4 split lanes, 4 independent loads in flight per lane
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
-                                                          int nsplit) {
-    __shared__ f32x4 red[4][64];
+// (device functions: the same code serves the one-layer kernels and the batched one; `blk` = block index inside the layer,
+// `red` = 8 KB of LDS)
+__device__ __forceinline__ void slab_reduce_block_f32(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
+                                                      int nsplit, int64_t blk, f32x4 (*red)[64]) {
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t i4 = (int64_t)blockIdx.x * 64 + cl;
+    const int64_t i4 = blk * 64 + cl;
     const int64_t n4 = n >> 2;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (i4 < n4) {
@@ -2422,6 +2480,71 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     if (sl == 0 && i4 < n4) reinterpret_cast<f32x4*>(out)[i4] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
+                                                          int nsplit) {
+    __shared__ f32x4 red[8][64];
+    slab_reduce_block_f32(slabs, out, n, nsplit, blockIdx.x, red);
+}
+
+// The same for slabs of bf16 pairs (conv3x3_wgrad_mfma_v2<.., SLAB16>): dword (cp, tap, ci) of a slab = rows 2 cp, 2 cp + 1 of one
+// (tap, ci).  npair = (Cout / 2) * row dwords per slab, row = 9 * Cin (a multiple of 4: a 16-byte piece stays inside one row pair).
+__device__ __forceinline__ void slab_reduce_block_bf16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
+                                                           int64_t npair, int row, int nsplit, int64_t blk, f32x4 (*red)[64]) {
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i4 = blk * 64 + cl;
+    const int64_t n4 = npair >> 2;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo, lo2 = lo, hi2 = lo;
+    auto add = [](f32x4& l, f32x4& h, const u32x4 v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { l[e] += __uint_as_float(v[e] << 16); h[e] += __uint_as_float(v[e] & 0xffff0000u); }
+    };
+    if (i4 < n4) {
+        const u32x4* base = reinterpret_cast<const u32x4*>(slabs) + i4;
+        int k = sl;
+        for (; k + 12 < nsplit; k += 16) {           // four independent loads in flight per lane, added in a fixed order
+            const u32x4 v0 = base[(int64_t)k * n4], v1 = base[(int64_t)(k + 4) * n4];
+            const u32x4 v2 = base[(int64_t)(k + 8) * n4], v3 = base[(int64_t)(k + 12) * n4];
+            add(lo, hi, v0); add(lo2, hi2, v1); add(lo, hi, v2); add(lo2, hi2, v3);
+        }
+        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4]);
+    }
+    red[sl][cl] = lo + lo2;
+    red[4 + sl][cl] = hi + hi2;
+    __syncthreads();
+    if (sl < 2 && i4 < n4) {                          // split lane 0 writes the even rows, lane 1 the odd ones
+        const int o = 4 * sl;
+        const f32x4 v = (red[o][cl] + red[o + 1][cl]) + (red[o + 2][cl] + red[o + 3][cl]);
+        const int64_t e = i4 << 2;                    // first dword of the piece
+        const int64_t cp = e / row, rem = e - cp * row;
+        *reinterpret_cast<f32x4*>(out + (2 * cp + sl) * row + rem) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_bf16pair_kernel(const unsigned* __restrict__ slabs, float* __restrict__ out,
+                                                                   int64_t npair, int row, int nsplit) {
+    __shared__ f32x4 red[8][64];
+    slab_reduce_block_bf16pair(slabs, out, npair, row, nsplit, blockIdx.x, red);
+}
+
+// Every pending slab reduction of a backward pass in ONE launch (uh_slab_reduce_batched): the filter gradients only feed the
+// optimizer, so the per-layer reduce launches -- eighteen 8-14 us kernels in the middle of the backward stream -- can wait until
+// the gradients are needed.  table[r] = { slabs, out, n, nsplit, format (0 fp32, 1 bf16 pairs), row, first block, 0 } (int64).
+constexpr int SLAB_TAB = 8;
+__global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t* __restrict__ table, int nrows) {
+    __shared__ f32x4 red[8][64];
+    const int64_t b = blockIdx.x;
+    int r = 0;
+    for (int k = 1; k < nrows; ++k)                   // (a few dozen rows at most; scalar loads)
+        if (table[k * SLAB_TAB + 6] <= b) r = k;
+    const int64_t* t = table + r * SLAB_TAB;
+    const int64_t blk = b - t[6];
+    if (t[4] == 0)
+        slab_reduce_block_f32(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[2], (int)t[3], blk, red);
+    else
+        slab_reduce_block_bf16pair(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]), t[2] / 2, (int)t[5],
+                                   (int)t[3], blk, red);
+}
+
 // =====================================================================================
 // backward-weights v2 (bf16): same MFMA mapping as conv3x3_wgrad_mfma, but 8-row pixel tiles whose two
 // [pixel][64 channel] LDS images (x halo 10x18, dy 8x16) are filled by LDS-DMA (buffer_load ... lds, zero
@@ -2437,7 +2560,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // front of the tile's barrier.  LDS is full (two workgroups x two stages = 160 KiB), so the 64 (scale, shift) pairs of the
 // workgroup's input-channel slab live in ONE register pair spread over the lanes (lane = channel) and reach the lane that needs
 // them through ds_bpermute (the LDS crossbar, no LDS memory).
-template <typename T, int NWR, bool PRE = false>
+// SLAB16: the per-split partial results go to the workspace as bf16 PAIRS (u32 = rows co, co + 1 of one (tap, ci)) instead of fp32:
+// half the 75 MB a launch writes and slab_reduce reads back.  Each partial is a sum over >= one tile of pixels accumulated in
+// fp32 by the MFMAs and rounded ONCE; slab_reduce adds the rounded partials in fp32 and the result stays fp32.  The reference
+// (train.py:116 autocast) rounds the TOTAL to bf16 -- conv backward returns the filter gradient in the dtype of the bf16 filter
+// copy -- so its error per element, 2^-9 |total|, is the error of nsplit rounded partials of random sign added in quadrature
+// and larger than ours when the partials agree in sign.  fp32 slabs: UH_WGRAD_SLAB_F32=1.
+template <typename T, int NWR, bool PRE = false, bool SLAB16 = false>
 __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
@@ -2672,7 +2801,10 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 #ifndef UH_WGRAD_ROT
 #define UH_WGRAD_ROT 1      // 1: the tile loop is rotated (see below); 0: one barrier at the very end of a tile (round 3)
 #endif
-#if UH_WGRAD_M16 && UH_WGRAD_ROT
+#if UH_WGRAD_M16
+    // (the consumer-side BatchNorm variants -- UH_BUILD_PRE -- keep the round-3 loop: their rewrite of the x image sits inside the
+    // fence, and inside the rotated MFMA stream it spills)
+    if constexpr (UH_WGRAD_ROT && !PRE) {
     // ROTATED tile loop.  A tile = six x row pairs a (fragments of pair a + 1 are fetched while pair a is multiplied; dy pair
     // p = a - r meets tap row r); the last LDS reads of a tile are those of pair 5, requested in front of pair 4's MFMAs.  The
     // end-of-tile fence (next tile's DMA landed, everyone done READING this buffer) therefore sits in front of pair 5's twelve
@@ -2743,7 +2875,9 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         __builtin_amdgcn_sched_barrier(0);
         mma_pair(5);
     }
-#else
+    } else
+#endif
+    {
     if (t_begin < t_end) issue(t_begin, 0);
     tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
@@ -2826,8 +2960,29 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 #endif
         tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
     }
-#endif
+    }
 
+#if UH_WGRAD_M16
+    if constexpr (SLAB16) {
+        // [co / 2][tap][ci] dwords: low half = row co (even), high half = row co + 1; a lane's accumulators j, j + 1 are such a pair
+        unsigned* slab16 = reinterpret_cast<unsigned*>(slabs) + (int64_t)split * (Cout / 2) * 9 * Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        const int co = co0 + wr * 32 + h * 16 + (lane >> 4) * 4 + jp;
+                        const int ci = ci0 + wc * 32 + hh * 16 + (lane & 15);
+                        const unsigned lo = __builtin_bit_cast(unsigned short, (bf16_t)acc[tap][h][hh][jp]);
+                        const unsigned hi = __builtin_bit_cast(unsigned short, (bf16_t)acc[tap][h][hh][jp + 1]);
+                        slab16[((int64_t)(co >> 1) * 9 + tap) * Cin + ci] = lo | (hi << 16);
+                    }
+        return;
+    }
+#endif
     float* slab = slabs + (int64_t)split * Cout * 9 * Cin;
 #if UH_WGRAD_M16
     // acc[tap][h][hh][j] = dW[co0 + wr*32 + h*16 + (lane >> 4)*4 + j][tap][ci0 + wc*32 + hh*16 + (lane & 15)]
@@ -3184,7 +3339,9 @@ template <typename T>
 static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, int ld0, const T* x1, int C1, int ld1,
                                   float* dw, int Cout, void* ws, size_t ws_bytes, int B, int H, int W, hipStream_t st,
                                   bool split = false, int C0v = -1, int C1v = -1, int Coutv = -1,
-                                  const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
+                                  const float* pre_scale = nullptr, const float* pre_shift = nullptr, int64_t* defer = nullptr) {
+    // defer != NULL (uh_conv3x3_wgrad_partials): the slab reduction is NOT launched; defer[0..7] describes it as a row of
+    // uh_slab_reduce_batched's table (defer[3] = 0: the path taken has no slabs, dw is final)
     constexpr int ES = sizeof(T);
     const int Cin = C0 + C1;
     const bool narrow = C0v >= 0;                 // tensors hold fewer channels than the filter is padded to
@@ -3219,6 +3376,8 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         uh_set_error("uh_conv3x3_wgrad_pre: needs the bf16 LDS-DMA kernel (64-aligned channels, tensors below 2 GiB); ask uh_conv3x3_pre_ok first");
         return UH_EINVAL;
     }
+    if (defer)
+        for (int k = 0; k < 8; ++k) defer[k] = 0;
     if (p.kind == 2) {
         hipLaunchKernelGGL(conv3x3_wgrad_generic<T>, dim3(Cout * 9), dim3(256), 0, st, dy, lddy, x0, C0, ld0, x1, C1, ld1,
                            dw, Cout, B, H, W);
@@ -3231,6 +3390,9 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         return UH_EWORKSPACE;
     }
     float* slabs = (float*)ws;
+    // bf16-pair slabs: the bf16 LDS-DMA kernel's default (see SLAB16)
+    static const bool slab_f32 = getenv("UH_WGRAD_SLAB_F32") != nullptr && getenv("UH_WGRAD_SLAB_F32")[0] == '1';
+    const bool slab16 = ES == 2 && p.kind == 0 && dma && !slab_f32 && UH_WGRAD_M16 && uh_aligned16(dw);
     if (p.kind == 0) {
         const int64_t npx = (int64_t)B * H * W;
         const int64_t ldmax = ld0 > ld1 ? ld0 : ld1;
@@ -3238,25 +3400,19 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
             if (dma) {
                 // byte extents of the (sliced) source views as seen from their base pointers
                 unsigned xb = (unsigned)(npx * ldmax * 2), db = (unsigned)(npx * lddy * 2);
+#define UH_LAUNCH_WGRAD_V2(NWR_, PRE_, S16_)                                                                                      \
+    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, NWR_, PRE_, S16_>), dim3(p.nsplit, (Cin / 64) * (Cout / (32 * NWR_))),           \
+                       dim3(128 * NWR_), 0, st, dy, lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY,      \
+                       p.nsplit, db, xb, C0v, C1v, Coutv, pre_scale, pre_shift)
 #if UH_BUILD_PRE
-                if (pre && p.nwr == 4)
-                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
-                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
-                                       C0v, C1v, Coutv, pre_scale, pre_shift);
-                else if (pre)
-                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 2, true>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
-                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
-                                       C0v, C1v, Coutv, pre_scale, pre_shift);
-                else
+                if (pre) {
+                    if (p.nwr == 4) { if (slab16) UH_LAUNCH_WGRAD_V2(4, true, true); else UH_LAUNCH_WGRAD_V2(4, true, false); }
+                    else { if (slab16) UH_LAUNCH_WGRAD_V2(2, true, true); else UH_LAUNCH_WGRAD_V2(2, true, false); }
+                } else
 #endif
-                if (p.nwr == 4)
-                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 4>), dim3(p.nsplit, (Cin / 64) * (Cout / 128)), dim3(512), 0, st, dy,
-                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
-                                       C0v, C1v, Coutv);
-                else
-                    hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, 2>), dim3(p.nsplit, (Cin / 64) * (Cout / 64)), dim3(256), 0, st, dy,
-                                       lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY, p.nsplit, db, xb,
-                                       C0v, C1v, Coutv);
+                if (p.nwr == 4) { if (slab16) UH_LAUNCH_WGRAD_V2(4, false, true); else UH_LAUNCH_WGRAD_V2(4, false, false); }
+                else { if (slab16) UH_LAUNCH_WGRAD_V2(2, false, true); else UH_LAUNCH_WGRAD_V2(2, false, false); }
+#undef UH_LAUNCH_WGRAD_V2
                 UH_CHECK_LAUNCH("conv3x3_wgrad_mfma_v2");
             }
         }
@@ -3294,6 +3450,19 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         }
     }
     int64_t n = (int64_t)Cout * 9 * Cin;      // multiple of 4 on every slab path (Cout % 64 == 0 or 9*... stem: Cout*9*Cin)
+    if (defer && n % 4 == 0 && uh_aligned16(dw) && uh_aligned16(slabs)) {
+        defer[0] = (int64_t)(uintptr_t)slabs; defer[1] = (int64_t)(uintptr_t)dw; defer[2] = n; defer[3] = p.nsplit;
+        defer[4] = slab16 ? 1 : 0; defer[5] = 9 * Cin;
+        defer[6] = slab16 ? (n / 2 / 4 + 63) / 64 : (n / 4 + 63) / 64;      // blocks of the reduction (the caller turns it into an offset)
+        return UH_OK;
+    }
+    if (slab16) {
+        const int64_t npair = n / 2;
+        hipLaunchKernelGGL(slab_reduce_bf16pair_kernel, dim3((unsigned)((npair / 4 + 63) / 64)), dim3(256), 0, st,
+                           (const unsigned*)slabs, dw, npair, 9 * Cin, p.nsplit);
+        UH_CHECK_LAUNCH("slab_reduce_bf16pair_kernel");
+        return UH_OK;
+    }
     if (n % 4 != 0 || !uh_aligned16(dw) || !uh_aligned16(slabs))
         hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const float*)slabs, dw, n, p.nsplit);
@@ -3318,6 +3487,36 @@ extern "C" int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0
                                               ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st);
     return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
                                          dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3);
+}
+
+// uh_conv3x3_wgrad without its last step: the contraction runs, the per-split partial results stay in `ws` (which must live until
+// the reduction has run) and desc[0..7] (HOST memory) receives the row of uh_slab_reduce_batched's table that finishes the job:
+// { slabs, dw, n, nsplit, format, row, number of blocks, 0 } -- the caller replaces desc[6] by the row's first block (running sum)
+// when it builds the table.  desc[3] == 0: this shape took a path without slabs, dw_krsc is already final.
+extern "C" int uh_conv3x3_wgrad_partials(const void* dy, int lddy, const void* x0, int C0, int ld0, const void* x1, int C1,
+                                         int ld1, float* dw_krsc, int Cout, void* ws, size_t ws_bytes, int B, int H, int W,
+                                         int dt, int64_t* desc, uh_stream stream) {
+    UH_REQUIRE(dy && x0 && dw_krsc && desc, "uh_conv3x3_wgrad_partials: null pointer");
+    UH_REQUIRE(B > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "uh_conv3x3_wgrad_partials: bad shape");
+    UH_REQUIRE(lddy >= Cout && ld0 >= C0 && (C1 == 0 || (x1 && ld1 >= C1)), "uh_conv3x3_wgrad_partials: bad strides");
+    UH_REQUIRE((int64_t)B * H * W < (1ll << 31), "uh_conv3x3_wgrad_partials: pixel count overflows int32");
+    UH_REQUIRE(dt == UH_F32 || dt == UH_BF16 || dt == UH_F32X3, "uh_conv3x3_wgrad_partials: bad dtype %d", dt);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == UH_BF16)
+        return conv3x3_wgrad_dispatch<bf16_t>((const bf16_t*)dy, lddy, (const bf16_t*)x0, C0, ld0, (const bf16_t*)x1, C1,
+                                              ld1, dw_krsc, Cout, ws, ws_bytes, B, H, W, st, false, -1, -1, -1, nullptr, nullptr, desc);
+    return conv3x3_wgrad_dispatch<float>((const float*)dy, lddy, (const float*)x0, C0, ld0, (const float*)x1, C1, ld1,
+                                         dw_krsc, Cout, ws, ws_bytes, B, H, W, st, dt == UH_F32X3, -1, -1, -1, nullptr, nullptr, desc);
+}
+
+// table: DEVICE memory, nrows x 8 int64 (rows as uh_conv3x3_wgrad_partials fills them, [6] = first block of the row);
+// total_blocks = sum of the rows' block counts.  One launch reduces every row: dw = sum over the splits, in the fixed order of
+// the per-layer kernels (bit-identical results).
+extern "C" int uh_slab_reduce_batched(const int64_t* table, int nrows, int64_t total_blocks, uh_stream stream) {
+    UH_REQUIRE(table && nrows > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "uh_slab_reduce_batched: bad arguments");
+    hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, nrows);
+    UH_CHECK_LAUNCH("slab_reduce_batched_kernel");
+    return UH_OK;
 }
 
 // Backward-weights of a layer whose forward was uh_conv3x3_fwd_pre: x0 is the RAW output of the previous conv and the layer's

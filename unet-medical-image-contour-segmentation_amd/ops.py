@@ -329,8 +329,80 @@ def conv3x3_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Te
     return y, stats, nslab
 
 
+class SlabBatch:
+    """Backward-weights reductions that wait for ONE launch (uh_conv3x3_wgrad_partials + uh_slab_reduce_batched).  A conv layer's
+    filter gradient only feeds the optimizer, so its closing reduction over the pixel splits -- one 8-14 us launch per layer, in
+    the middle of the backward stream -- is queued here instead, with the callback that tells the optimizer (and the gradient
+    all-reduce) that the parameter's gradient is final, and flush() runs them all.  The partial results live in workspaces this
+    object owns, one per destination (they are written in one step and read at the flush of the same step).
+    `flush_bytes`: flush as soon as that many bytes of gradients are pending (data parallel: one bucket's worth, so that the
+    bucket's all-reduce can start under the rest of the backward pass); None: only when asked (TrainStepper: after backward)."""
+
+    def __init__(self, flush_bytes: Optional[int] = None):
+        self.flush_bytes = flush_bytes
+        self.arena = {}
+        self.rows, self.callbacks = [], []
+        self.pending_bytes = 0
+        self._table_key = None
+        self._table = None
+
+    def workspace(self, key, nbytes: int, device) -> torch.Tensor:
+        ws = self.arena.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = self.arena[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
+
+    def add(self, desc, callback):
+        self.rows.append(tuple(desc))
+        self.callbacks.append(callback)
+        self.pending_bytes += 4 * int(desc[2])
+        if self.flush_bytes is not None and self.pending_bytes >= self.flush_bytes:
+            self.flush()
+
+    def reset(self):
+        self.rows, self.callbacks, self.pending_bytes = [], [], 0
+
+    def flush(self):
+        if not self.rows:
+            return
+        key = tuple(self.rows)
+        if key != self._table_key:
+            # (same layers, same buffers every step: the table is uploaded once; a captured graph replays with it)
+            tab, off = [], 0
+            for r in self.rows:
+                tab.append([r[0], r[1], r[2], r[3], r[4], r[5], off, 0])
+                off += r[6]
+            dev = next(iter(self.arena.values())).device
+            self._table = (torch.tensor(tab, dtype=torch.int64).to(dev), len(tab), off)
+            self._table_key = key
+        table, nrows, blocks = self._table
+        with _Timed("slab_reduce_batched", 0.0):
+            LIB.call("uh_slab_reduce_batched", table.data_ptr(), nrows, blocks, _stream())
+        cbs = self.callbacks
+        self.reset()
+        for cb in cbs:
+            if cb is not None:
+                cb(None)
+
+
+# set by TrainStepper for the duration of a step; None = every backward-weights call reduces its own slabs at once
+SLAB_BATCH: Optional[SlabBatch] = None
+# OFF by default -- measured (round 4, one MI355X, config 2, three interleaved rounds, bf16 slabs): 873.1 images/s with the
+# per-layer launches, 872.2 with one batched launch behind the backward pass (B=4: 763.0 / 762.2).  The eighteen launches it
+# removes are bandwidth-bound (37 MB each at 5.5 TB/s), not latency-bound, and a layer's slabs are read back from the Infinity
+# Cache when the reduction runs at once, from HBM when it runs a millisecond later.  UH_DEFER_SLABS=1 turns it on.
+DEFER_SLABS = os.environ.get("UH_DEFER_SLABS", "0") == "1"
+
+
+def flush_slabs():
+    if SLAB_BATCH is not None:
+        SLAB_BATCH.flush()
+
+
 def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], out_krsc: torch.Tensor,
-                  split: bool = False):
+                  split: bool = False, defer_cb=None) -> bool:
+    """dW (fp32 KRSC) of a 3x3 conv.  `defer_cb` (a callable taking one argument): the caller allows the closing reduction to be
+    queued in ops.SLAB_BATCH; the callback then fires when it has run.  -> True when the result (and the callback) were deferred."""
     B, H, W, Cout = dy.shape
     C0 = x0.shape[3]
     C1 = 0 if x1 is None else x1.shape[3]
@@ -338,12 +410,25 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
     nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", B, H, W, C0 + C1, Cout, dt)
     if split and dt == UH_F32 and C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0:
         dt = UH_F32X3                          # bf16x3 products (ops.FP32_MODE); same workspace as the fp32 plan
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     name = "conv3x3_wgrad_" + ("mfma" if (C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0) else
                                 ("stem" if C0 + C1 <= 4 else "generic"))
+    batch = SLAB_BATCH if (defer_cb is not None and DEFER_SLABS and name == "conv3x3_wgrad_mfma") else None
+    if batch is not None:
+        ws = batch.workspace(out_krsc.data_ptr(), nbytes, dy.device)
+        desc = (ctypes.c_int64 * 8)()
+        with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1), ("wgrad", B, H, W, C0 + C1, Cout)):
+            LIB.call("uh_conv3x3_wgrad_partials", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
+                     0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt,
+                     ctypes.addressof(desc), _stream())
+        if desc[3] == 0:                       # a path without slabs: the gradient is final
+            return False
+        batch.add(list(desc), defer_cb)
+        return True
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     with _Timed(name, 2.0 * B * H * W * Cout * 9 * (C0 + C1), ("wgrad", B, H, W, C0 + C1, Cout)):
         LIB.call("uh_conv3x3_wgrad", dy.data_ptr(), pixel_ld(dy), x0.data_ptr(), C0, pixel_ld(x0), _p(x1), C1,
                  0 if x1 is None else pixel_ld(x1), out_krsc.data_ptr(), Cout, ws.data_ptr(), nbytes, B, H, W, dt, _stream())
+    return False
 
 
 def conv3x3_wgrad_pre(dy: torch.Tensor, x0_raw: torch.Tensor, pre_coef: torch.Tensor, out_krsc: torch.Tensor):
@@ -798,11 +883,11 @@ class ConvBnReluFn(Function):
         dweight = None
         side_done = None
 
-        def run_wgrad(out_):
+        def run_wgrad(out_, defer_cb=None):
             if pre_coef is None:
-                conv3x3_wgrad(dy, x0, x1, out_, ctx.cdt == UH_F32X3)
-            else:
-                conv3x3_wgrad_pre(dy, x0, pre_coef, out_)
+                return conv3x3_wgrad(dy, x0, x1, out_, ctx.cdt == UH_F32X3, defer_cb)
+            conv3x3_wgrad_pre(dy, x0, pre_coef, out_)
+            return False
 
         if ctx.needs_input_grad[2]:
             dweight, cb_w = _grad_buffer(weight)
@@ -819,7 +904,11 @@ class ConvBnReluFn(Function):
                     if t_ is not None:
                         t_.record_stream(side)      # the caching allocator must not recycle them under the side stream
             elif _is_krsc_dense(weight):
-                run_wgrad(dweight)
+                # (straight into the optimizer's flat buffer: the closing reduction may wait for the batched launch, and the
+                # "gradient ready" callback with it)
+                if run_wgrad(dweight, cb_w):
+                    cb_w = None
+                    dweight = None
             else:
                 dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
                 run_wgrad(dwk)

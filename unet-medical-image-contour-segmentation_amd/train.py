@@ -203,6 +203,7 @@ class FusedRMSprop:
     def step(self):
         if self._closed:
             raise RuntimeError("FusedRMSprop.step() after close() (another FusedRMSprop took the parameters over)")
+        ops.flush_slabs()
         if ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)     # weight gradients written on the side stream
         # A parameter that received no gradient this step is SKIPPED, as torch.optim skips parameters whose .grad is None
@@ -348,6 +349,7 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
     optimizer.zero_grad(set_to_none=True)
     # (the seed gradient is a cached constant: loss.backward() alone launches a fill kernel for it every step)
     loss.backward(gradient=_one_like(loss))
+    ops.flush_slabs()            # the backward-weights reductions that waited for one batched launch (ops.SlabBatch)
     if nan_event is not None:
         nan_event.synchronize()
         if float(nan_host.item()) > 0:
@@ -409,6 +411,10 @@ class TrainStepper:
         self.optimizer = FusedRMSprop(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
                                       gradient_clipping=gradient_clipping, process_group=process_group)
         self._pack = None
+        # the closing reductions of backward-weights wait for one batched launch behind the backward pass; data parallel: for
+        # one launch per gradient bucket, so that the bucket's all-reduce still starts under the rest of the backward pass
+        sync = self.optimizer.sync
+        self._slabs = ops.SlabBatch(flush_bytes=None if sync is None else 8 << 20)
 
     def close(self):
         """Release what the stepper owns outside torch's garbage collection: the optimizer's hooks and, when SyncBN runs on
@@ -453,8 +459,13 @@ class TrainStepper:
         if self._pack is not None:
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
-        return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
-                          reduce_sums=self.reduce_sums, world=world, check_nan=self.check_nan, cc_loss=self.cc_loss)
+        self._slabs.reset()
+        ops.SLAB_BATCH = self._slabs if self.wgrad_stream is None else None
+        try:
+            return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
+                              reduce_sums=self.reduce_sums, world=world, check_nan=self.check_nan, cc_loss=self.cc_loss)
+        finally:
+            ops.SLAB_BATCH = None
 
 
 class GraphedTrainStepper(TrainStepper):
@@ -485,8 +496,13 @@ class GraphedTrainStepper(TrainStepper):
         if self._pack is not None:
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
-        return train_step(self.model, self.optimizer, images, masks, amp=self.amp, reduce_sums=self.reduce_sums,
-                          world=self.world, check_nan=False)
+        self._slabs.reset()
+        ops.SLAB_BATCH = self._slabs if self.wgrad_stream is None else None
+        try:
+            return train_step(self.model, self.optimizer, images, masks, amp=self.amp, reduce_sums=self.reduce_sums,
+                              world=self.world, check_nan=False)
+        finally:
+            ops.SLAB_BATCH = None
 
     def _capture(self, images, masks):
         opt = self.optimizer
