@@ -10,141 +10,102 @@
 #include "uh_vec.h"
 
 // ------------------------------------------------------------------------------------ finalize
-// Slab layout written by the conv epilogue: [nslab][2][C] = per-tile (mean, M2) of the stored y, followed
-// by [nslab] pixel counts.  Tiles are merged with Chan's parallel-variance formula in double.
-struct Moments { double n, mean, m2; };
-__device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, double m2b) {
-    if (nb <= 0.0) return;
-    double n = a.n + nb;
-    double d = mb - a.mean;
-    a.mean += d * (nb / n);
-    a.m2 += m2b + d * d * (a.n * nb / n);
-    a.n = n;
-}
+// Slab layout written by the conv epilogue: [nslab][2][C] = per-row (mean, M2) of the stored y, followed
+// by [nslab] pixel counts (one row per workgroup of the MFMA kernels, per tile of the others).
 
 // Rows with a zero pixel count are skipped (producers that use fewer rows than the buffer holds zero the counts of the rest).
-// Two-pass merge in double (mean, then M2 about it), then the affine coefficients, the running statistics and num_batches_tracked.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int ldc, int C, double n,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ rmean,
-                                                           float* __restrict__ rvar, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                           long long* __restrict__ nbt, float* __restrict__ m2_o) {
-    // block = 16 channels x 64 row lanes (C/16 blocks, each thread walks R/64 rows)
-    __shared__ double red[3][16][16];
-    __shared__ int last_row;
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 16 + cl;
-    const float* cnt = stats + (int64_t)nslab * 2 * ldc;      // ldc: channels per stat row (>= C)
-    // Every thread owns rows sl, sl + 64, ...  The rows were written by the previous kernel from all eight XCDs, so every
-    // load here is an HBM / MALL round trip, and the kernel is nothing but dependent round trips.  The MFMA conv kernels write at
-    // most 768 live rows (one per workgroup) into a buffer sized for one row per TILE, so the first FAST_ROWS rows are fetched
-    // unconditionally -- 12 per thread, clamped index, no branch in between, the count tests applied to the VALUES -- in the SAME
-    // round trip in which the counts of all the rows behind them are scanned.  Only a producer with more live rows than that
-    // (the per-tile statistics of the generic kernels) takes the second trip: find the last live row, walk the rest in batches.
-    // Cross-lane sums: the 4 row lanes of a wave by shuffles (lane bits 4,5), the 16 waves through LDS.
-    auto block_sum = [&](double v, int slot) -> double {
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if ((threadIdx.x & 63) < 16) red[slot][wave][cl] = v;
-        __syncthreads();
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[slot][k][cl];
-        return t;
-    };
-    constexpr int MAXI = 12, FAST_ROWS = 64 * MAXI;
+// One-pass merge in double about a pivot (the first row's mean): N = sum n_i, A = sum n_i (m_i - p), S = sum M2_i,
+// Q = sum n_i (m_i - p)^2  ->  mean = p + A / N,  M2 = S + Q - A^2 / N; then the affine coefficients, the running statistics and
+// num_batches_tracked.
+//
+// This kernel is nothing but latency on the critical path of the forward pass (launch, one dependent round trip to rows that
+// all eight XCDs wrote, a cross-wave reduction, a handful of stores): 18 launches per train step.  Round 3's form (1024-thread
+// blocks of 16 channels, a scan of ALL the per-tile counts for the last live row, then a two-pass merge: five block-wide
+// barriers over 16 waves) took 8.5-13 us; now: 256-thread blocks of 4 channels x 64 row lanes, the first 1024 rows fetched
+// unconditionally in ONE batch (16 per thread: the MFMA conv kernels write one row per workgroup, at most 768, the recomputed
+// stem at most 1024), ONE reduction phase (four sums at once, one barrier over four waves) -- and the rows behind the first
+// 1024 are only walked when the pixel count the caller passed does not match what those rows hold (producers with one row
+// per tile: the generic / >= 2 GiB kernels).
+constexpr int BNF_CH = 4, BNF_RL = 64, BNF_MAXI = 16, BNF_FAST = BNF_RL * BNF_MAXI;      // 1024 rows in the first batch
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nslab, int ldc, int C, double n,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float momentum, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                          long long* __restrict__ nbt, float* __restrict__ m2_o) {
+    __shared__ double red[4][4][BNF_CH];          // [wave][sum][channel]
+    const int cl = threadIdx.x & (BNF_CH - 1), sl = threadIdx.x / BNF_CH, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * BNF_CH + cl;
     const int cc = c < C ? c : C - 1;
-    if (threadIdx.x == 0) last_row = -1;
-    float nfr[MAXI], mvr[MAXI], m2r[MAXI];
-    const int R0 = nslab < FAST_ROWS ? nslab : FAST_ROWS;
+    const float* cnt = stats + (int64_t)nslab * 2 * ldc;      // ldc: channels per stat row (>= C)
+    // the first batch: clamped row index, no branch between the loads, the count tests applied to the VALUES
+    float nfr[BNF_MAXI], mvr[BNF_MAXI], m2r[BNF_MAXI];
+    const int R0 = nslab < BNF_FAST ? nslab : BNF_FAST;
+    const float cnt0 = cnt[0], mean0 = stats[cc];
 #pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-        const int f = sl + 64 * i;
+    for (int i = 0; i < BNF_MAXI; ++i) {
+        const int f = sl + BNF_RL * i;
         const int fc = f < R0 ? f : R0 - 1;
         nfr[i] = cnt[fc];
         mvr[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
         m2r[i] = stats[((int64_t)fc * 2 + 1) * ldc + cc];
         if (f >= R0) nfr[i] = 0.f;
     }
-    int last = -1;
-    for (int s0 = FAST_ROWS + threadIdx.x; s0 < nslab; s0 += 8 * 1024) {      // eight independent loads per trip (8 192 tiles: one trip)
-        float v[8];
+    const double piv = cnt0 > 0.f ? (double)mean0 : 0.0;      // (a dead first row may hold anything)
+    double sN = 0.0, sA = 0.0, sS = 0.0, sQ = 0.0;
+    auto take = [&](float nf_, float mv_, float m2_) {
+        const bool live = nf_ > 0.f;               // rows with a zero count may hold anything
+        const double nf = (double)nf_, d = (double)mv_ - piv;
+        sN = live ? sN + nf : sN;
+        sA = live ? fma(nf, d, sA) : sA;
+        sS = live ? sS + (double)m2_ : sS;
+        sQ = live ? fma(nf * d, d, sQ) : sQ;
+    };
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = s0 + u * 1024;
-            v[u] = cnt[idx < nslab ? idx : nslab - 1];
+    for (int i = 0; i < BNF_MAXI; ++i) take(nfr[i], mvr[i], m2r[i]);
+    // the 16 row lanes of a wave by shuffles (lane bits 2..5), the 4 waves through LDS -- sums in a fixed order
+    auto block_sums = [&](double& N, double& A, double& S, double& Q) {
+#pragma unroll
+        for (int o = BNF_CH; o < 64; o <<= 1) {
+            sN += __shfl_xor(sN, o, 64); sA += __shfl_xor(sA, o, 64); sS += __shfl_xor(sS, o, 64); sQ += __shfl_xor(sQ, o, 64);
         }
+        if ((threadIdx.x & 63) < BNF_CH) { red[wave][0][cl] = sN; red[wave][1][cl] = sA; red[wave][2][cl] = sS; red[wave][3][cl] = sQ; }
+        __syncthreads();
+        N = (red[0][0][cl] + red[1][0][cl]) + (red[2][0][cl] + red[3][0][cl]);
+        A = (red[0][1][cl] + red[1][1][cl]) + (red[2][1][cl] + red[3][1][cl]);
+        S = (red[0][2][cl] + red[1][2][cl]) + (red[2][2][cl] + red[3][2][cl]);
+        Q = (red[0][3][cl] + red[1][3][cl]) + (red[2][3][cl] + red[3][3][cl]);
+    };
+    double N, A, S, Q;
+    block_sums(N, A, S, Q);
+    if (nslab > BNF_FAST && !(n > 0.0 && N == n)) {           // (block-uniform: the counts do not depend on the channel)
+        // live rows behind the first batch (one row per TILE): walk them all, batches of BNF_MAXI rows per thread
+        __syncthreads();                                       // `red` is read above
+        sN = sA = sS = sQ = 0.0;
+        for (int base = BNF_FAST; base < nslab; base += BNF_FAST) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = s0 + u * 1024;
-            if (idx < nslab && v[u] > 0.f) last = idx;
-        }
-    }
-    __syncthreads();                                  // last_row initialised
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    if ((threadIdx.x & 63) == 0 && last >= 0) atomicMax(&last_row, last);
-    __syncthreads();
-    const int R = last_row + 1;                       // 0: every live row is among the first FAST_ROWS
-    const bool single = R <= FAST_ROWS;
-    double a = 0.0, cn = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-        const double nf = (double)nfr[i];
-        const bool live = nfr[i] > 0.f;                // rows with a zero count may hold anything
-        a = live ? fma(nf, (double)mvr[i], a) : a;
-        cn = live ? cn + nf : cn;
-    }
-    for (int base = FAST_ROWS; base < R; base += FAST_ROWS) {
-        float nf2[MAXI], mv2[MAXI];
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int f = base + sl + 64 * i;
-            const int fc = f < R ? f : R - 1;
-            nf2[i] = f < R ? cnt[fc] : 0.f;
-            mv2[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
-        }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const double nf = (double)nf2[i];
-            a = nf2[i] > 0.f ? fma(nf, (double)mv2[i], a) : a;
-            cn = nf2[i] > 0.f ? cn + nf : cn;
-        }
-    }
-    const double A = block_sum(a, 0), N = block_sum(cn, 1);
-    const double mean = N > 0.0 ? A / N : 0.0;
-    double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {                   // the first FAST_ROWS rows: still in registers
-        const double nf = (double)nfr[i];
-        const double d = (double)mvr[i] - mean;
-        q = nfr[i] > 0.f ? q + ((double)m2r[i] + nf * d * d) : q;
-    }
-    if (!single) {
-        for (int base = FAST_ROWS; base < R; base += FAST_ROWS) {
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const int f = base + sl + 64 * i;
-                const int fc = f < R ? f : R - 1;
-                nfr[i] = f < R ? cnt[fc] : 0.f;
+            for (int i = 0; i < BNF_MAXI; ++i) {
+                const int f = base + sl + BNF_RL * i;
+                const int fc = f < nslab ? f : nslab - 1;
+                nfr[i] = f < nslab ? cnt[fc] : 0.f;
                 mvr[i] = stats[((int64_t)fc * 2 + 0) * ldc + cc];
                 m2r[i] = stats[((int64_t)fc * 2 + 1) * ldc + cc];
             }
 #pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const double nf = (double)nfr[i];
-                const double d = (double)mvr[i] - mean;
-                q = nfr[i] > 0.f ? q + ((double)m2r[i] + nf * d * d) : q;
-            }
+            for (int i = 0; i < BNF_MAXI; ++i) take(nfr[i], mvr[i], m2r[i]);
         }
+        double N2, A2, S2, Q2;
+        block_sums(N2, A2, S2, Q2);
+        N += N2; A += A2; S += S2; Q += Q2;
     }
-    Moments m = {N, mean, block_sum(q, 2)};
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;            // unet_parts.py:16: BatchNorm2d bookkeeping
     if (sl != 0 || c >= C) return;
+    const double mean = N > 0.0 ? piv + A / N : 0.0;
+    double m2 = N > 0.0 ? S + Q - A * A / N : 0.0;
+    if (m2 < 0.0) m2 = 0.0;
     if (n <= 0.0) n = N;                        // caller did not know the pixel count: the counted total
-    double var = m.m2 / n;                      // biased
+    double var = m2 / n;                        // biased
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma[c], bt = beta[c];
     float sc = g * rstd;
@@ -152,10 +113,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     shift[c] = bt - (float)mean * sc;
     mean_o[c] = (float)mean;
     rstd_o[c] = rstd;
-    if (m2_o) m2_o[c] = (float)m.m2;
+    if (m2_o) m2_o[c] = (float)m2;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
     if (rvar) {
-        double unb = n > 1.0 ? m.m2 / (n - 1.0) : var;
+        double unb = n > 1.0 ? m2 / (n - 1.0) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
 }
@@ -167,7 +128,7 @@ extern "C" int uh_bn_finalize(const float* stat_partials, int nslab, int C, int6
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize: null pointer");
     UH_REQUIRE(nslab > 0 && C > 0 && n >= 0, "uh_bn_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, C, C, (double)n, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BNF_CH - 1) / BNF_CH), dim3(256), 0, st, stat_partials, nslab, C, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
                        (long long*)num_batches_tracked, m2_out);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
@@ -184,7 +145,7 @@ extern "C" int uh_bn_finalize_ld(const float* stat_partials, int nslab, int ldc,
     UH_REQUIRE(stat_partials && gamma && beta && scale && shift && mean && rstd, "uh_bn_finalize_ld: null pointer");
     UH_REQUIRE(nslab > 0 && C > 0 && ldc >= C && n >= 0, "uh_bn_finalize_ld: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, stat_partials, nslab, ldc, C, (double)n, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BNF_CH - 1) / BNF_CH), dim3(256), 0, st, stat_partials, nslab, ldc, C, (double)n, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
                        (long long*)num_batches_tracked, m2_out);
     UH_CHECK_LAUNCH("bn_finalize_kernel");
