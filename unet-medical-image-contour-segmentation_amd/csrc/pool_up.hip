@@ -169,19 +169,23 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 
 // Same arithmetic, far fewer instructions per byte written (the grid-stride form above spends ~200 VALU instructions --
 // 64-bit div / mod, coordinates, four 8-value unpacks -- on every 16 bytes and runs at 2.9 TB/s: instruction-bound).
-// Here a workgroup row (blockIdx.x) is FOUR consecutive output rows of one image: the row decode and the vertical
-// coordinates are scalar, a thread = (output column, 16-byte channel group) loads the input rows those four output
-// rows touch (x 2 columns; at most 4), interpolates them horizontally once, and blends each output row from two of the three
-// horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
+// Here a workgroup row (blockIdx.x) is UP_ROWS consecutive output rows of one image: the row decode and the vertical
+// coordinates are scalar, a thread = (output column, 16-byte channel group) loads the input rows those output
+// rows touch (x 2 columns; at most UP_ROWS / 2 + 2), interpolates them horizontally once, and blends each output row from two of
+// the horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
 // PRE: x is the RAW output of a conv and the activation that is up-sampled, max(x * scale + shift, 0) rounded to T exactly as
 // uh_bn_relu_apply would have stored it, is formed on the way in (uh_bn_relu_upsample2x_fwd: that activation has no other reader).
+// Output rows per thread.  The kernel is VALU-bound, not HBM-bound (550 instructions per four 16-byte stores = 3.6 TB/s of tensor
+// bytes, measured 3.6): the BatchNorm + ReLU + rounding of the PRE form is applied to every LOADED value, and eight output rows
+// touch six input rows where two groups of four touch eight.
+constexpr int UP_ROWS = 4;
 template <typename T, int V, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                                   int h, int w, int C, int Ho, int Wo, int pt, int pl,
                                                                   float sy, float sx, int gshift,
                                                                   const float* __restrict__ pre_scale = nullptr,
                                                                   const float* __restrict__ pre_shift = nullptr) {
-    constexpr int R = 4;
+    constexpr int R = UP_ROWS;
     const int G = C / V;
     const int groups = (Ho + R - 1) / R;
     const int b = blockIdx.x / groups, oy0 = (blockIdx.x - b * groups) * R;
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
         cy[r] = up_coord(row_in[r] ? uy : 0, sy, h);
         if (row_in[r] && cy[r].i0 < base) base = cy[r].i0;
     }
-    // four output rows advance the source row by < 1.5, so they touch input rows base .. base+3 at most
-    constexpr int NR = 4;
-    float hr[NR][V];                                   // horizontally interpolated input rows base .. base+3
+    // R output rows advance the source row by < (R - 1) / 2, so they touch input rows base .. base + R / 2 + 1 at most
+    constexpr int NR = R / 2 + 2;
+    float hr[NR][V];                                   // horizontally interpolated input rows base .. base + NR - 1
     if (col_in) {
         const UpCoord cx = up_coord(ux, sx, w);
         float sc[PRE ? V : 1], sh[PRE ? V : 1];
@@ -240,11 +244,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
             const int a = cy[r].i0 - base, bb = cy[r].i1 - base;      // in 0..3, uniform over the workgroup: scalar branches
             const float l0 = cy[r].l0, l1 = cy[r].l1;
             float ra[V], rb[V];
-            auto pick = [&](int k, float (&dst)[V]) {
-                if (k == 0) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[0][i]; }
-                else if (k == 1) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[1][i]; }
-                else if (k == 2) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[2][i]; }
-                else { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[3][i]; }
+            auto pick = [&](int k, float (&dst)[V]) {              // k is uniform over the workgroup: a chain of scalar branches
+                _Pragma("unroll") for (int j = 0; j < NR; ++j)
+                    if (k == j || (j == NR - 1 && k >= NR)) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[j][i]; }
             };
             pick(a, ra);
             pick(bb, rb);
@@ -444,7 +446,7 @@ extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B
             for (int k = 0; k < 24; ++k)
                 if ((1 << k) == G) gshift = k;
             const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
-            hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * ((Ho + 3) / 4)), gy), dim3(256), 0, st, (const T*)x,
+            hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
                                ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift);
         } else if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
             hipLaunchKernelGGL((upsample2x_fwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
@@ -482,7 +484,7 @@ extern "C" int uh_bn_relu_upsample2x_fwd(const void* x, int ldx, const float* sc
         for (int k = 0; k < 24; ++k)
             if ((1 << k) == G) gshift = k;
         const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
-        hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC, true>), dim3((unsigned)(B * ((Ho + 3) / 4)), gy), dim3(256), 0, st, (const T*)x,
+        hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC, true>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
                            ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift, scale, shift);
     });
     UH_CHECK_LAUNCH("upsample2x_fwd_rows_kernel (BatchNorm + ReLU input)");
