@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 // the horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
 // PRE: x is the RAW output of a conv and the activation that is up-sampled, max(x * scale + shift, 0) rounded to T exactly as
 // uh_bn_relu_apply would have stored it, is formed on the way in (uh_bn_relu_upsample2x_fwd: that activation has no other reader).
-// Output rows per thread.  The kernel is VALU-bound, not HBM-bound (550 instructions per four 16-byte stores = 3.6 TB/s of tensor
-// bytes, measured 3.6): the BatchNorm + ReLU + rounding of the PRE form is applied to every LOADED value, and eight output rows
-// touch six input rows where two groups of four touch eight.
+// Output rows per thread.  Eight rows (six input rows instead of two groups of four, a quarter fewer loads and BatchNorm + ReLU +
+// rounding operations per stored value) measured no different from four on the four Up-block shapes of config 2 (round 4,
+// scratch/r4_upbench.py: 188.3 vs 188.6 us in all, 3.2-3.9 TB/s of tensor bytes): the kernel is not waiting for its VALU work.
 constexpr int UP_ROWS = 4;
 template <typename T, int V, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
