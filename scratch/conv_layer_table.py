@@ -13,12 +13,16 @@ B = 8
 
 
 def is_bnsum(name: str) -> bool:
-    """last template argument (BSUM) of conv3x3_fwd_mfma_v2, mangled or demangled spelling"""
-    m = re.search(r"ELb([01])EEvPKT", name)
+    """the BSUM template argument of conv3x3_fwd_mfma_v2 (second to last since round 4: <T, NBW, SPLIT, WRES, PRE, BSUM, KS>),
+    mangled or demangled spelling"""
+    m = re.search(r"ELb([01])ELi[12]EEvPKT", name) or re.search(r"ELb([01])EEvPKT", name)
     if m:
         return m.group(1) == "1"
     m = re.search(r"conv3x3_fwd_mfma_v2<([^>]*)>", name)
-    return bool(m) and m.group(1).split(",")[-1].strip() == "true"
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(1).split(",")]
+    return (args[-2] if args[-1] in ("1", "2") else args[-1]) == "true"
 
 
 def main():

@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = [
     # backward-data launches that also form BatchNorm-backward sums (last template argument of conv3x3_fwd_mfma_v2, mangled or not):
     # a family of their own, like in bench.py's kernel profile -- they read one more tensor than the plain kernel
-    ("conv3x3_dgrad_bnsum_mfma", r"conv3x3_fwd_mfma_v2I\w+?ELb1EEvPKT|conv3x3_fwd_mfma_v2<[^>]*true>"),
-    ("conv3x3_fwd_mfma", r"conv3x3_fwd_mfma_v2"), ("conv3x3_wgrad_mfma", r"conv3x3_wgrad_mfma_v2"), ("slab_reduce", r"slab_reduce_kernel"),
+    ("conv3x3_dgrad_bnsum_mfma", r"conv3x3_fwd_mfma_v2I\w+?ELb1ELi[12]EEvPKT|conv3x3_fwd_mfma_v2I\w+?ELb1EEvPKT|conv3x3_fwd_mfma_v2<[^>]*true, [12]>|conv3x3_fwd_mfma_v2<[^>]*true>"),
+    ("conv3x3_fwd_mfma", r"conv3x3_fwd_mfma_v2"), ("conv3x3_wgrad_mfma", r"conv3x3_wgrad_mfma_v2"), ("slab_reduce", r"slab_reduce_\w*kernel"),
     ("bn_relu_pool_apply", r"bn_relu_pool_apply_kernel"), ("bn_relu_pool_bwd_apply", r"bn_relu_pool_bwd_apply_kernel"),
     ("bn_relu_pool_bwd_reduce", r"bn_relu_pool_bwd_reduce_kernel"), ("bn_relu_head_fwd", r"bn_relu_head_fwd_kernel"),
     ("bn_relu_head_bwd_apply", r"bn_relu_head_bwd_apply_kernel"), ("bn_relu_head_bwd_reduce", r"bn_relu_head_bwd_reduce_kernel"),
@@ -18,7 +18,7 @@ FAMILIES = [
     ("upsample2x_bwd", r"upsample2x_bwd"), ("stem_recompute", r"stem_mfma_kernel"), ("conv3x3_fwd_stem", r"conv3x3_fwd_stem"), ("conv3x3_wgrad_stem", r"conv3x3_wgrad_stem"),
     ("conv1x1_fwd", r"conv1x1_fwd"), ("conv1x1_dgrad", r"conv1x1_dgrad_kernel"), ("conv1x1_wgrad", r"conv1x1_wgrad_kernel"),
     ("rmsprop", r"rmsprop_kernel"), ("grad_sumsq", r"grad_sumsq_kernel"), ("pack_w3x3_batched", r"pack_w3x3_batched_kernel"),
-    ("bce_dice_sums", r"bce_dice_sums_kernel"), ("boundary_count", r"boundary_count_kernel"),
+    ("bce_dice_sums", r"bce_dice_(mm_)?sums_kernel"), ("boundary_count", r"boundary_count_kernel"),
 ]
 # UNet(1,1,bilinear) B=8 512^2: the 17 MFMA 3x3 layers in forward order: (name, H, Cin, Cout)
 LAYERS = [("inc.3", 512, 64, 64), ("down1.0", 256, 64, 128), ("down1.3", 256, 128, 128), ("down2.0", 128, 128, 256), ("down2.3", 128, 256, 256),
@@ -34,7 +34,7 @@ def rows_of(d):
 
 def main():
     dfetch, dwrite, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.json")
+    out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r04_hbm_traffic_pmc.json")
     rf, rw = rows_of(dfetch), rows_of(dwrite)
 
     def agg(rows, counter):
