@@ -305,6 +305,56 @@ def test_wgrad_stream_choice_is_per_stepper():
     torch.cuda.synchronize()
 
 
+def _stale_pattern_worker(rank, world, port, q, mode):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import unet_amd
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
+        opt = unet_amd.FusedRMSprop(model.parameters(), lr=1e-4)
+        assert opt.sync is not None
+        frozen = model.up2.conv.double_conv[4].weight            # a BatchNorm gamma: its gradient goes through the accumulate hook
+        im, mk = unet_amd.ellipse_batch(4, 64, seed=5)
+        im, mk = im[rank * 2:rank * 2 + 2].to(dev), mk[rank * 2:rank * 2 + 2].to(dev)
+        err = None
+        for step in range(2):
+            # mode "rank": the parameter is frozen on rank 1 only, from the first step; mode "later": on both ranks, from step 1
+            frozen.requires_grad_(not ((mode == "rank" and rank == 1) or (mode == "later" and step == 1)))
+            model.train()
+            opt.zero_grad()
+            unet_amd.seg_loss(model(im), mk, 1, reduce_sums=unet_amd.dp.make_sum_reducer(None), world=world)["loss"].backward()
+            try:
+                opt.step()
+            except RuntimeError as e:
+                err = (step, str(e))
+                break
+        torch.cuda.synchronize()
+        q.put((rank, "ok", err))
+        os._exit(0)          # (a bucket all-reduce may still be pending on the rank that saw every gradient: do not wait for it)
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("mode", ["rank", "later"])
+def test_a_parameter_stale_on_one_rank_only_is_refused(mode):
+    """torch.optim behind DDP updates a parameter on every rank or on none (the all-reduce makes .grad non-None everywhere); the
+    fused optimizer skips locally stale slices, so a parameter that is fresh on one rank and stale on another would diverge
+    silently.  The pattern is agreed on the first step (both ranks raise) and may not change later (a local test: no rank is left
+    waiting at a collective the others skip)."""
+    res = _spawn(_stale_pattern_worker, mode)
+    for rank, _, err in res:
+        assert err is not None, f"rank {rank} stepped although the ranks disagree"
+        step, msg = err
+        if mode == "rank":
+            assert step == 0 and "some ranks" in msg, (rank, err)
+        else:
+            assert step == 1 and "changed between steps" in msg, (rank, err)
+
+
 # ------------------------------------------------------------------------------------------ the real backend, one rank
 def _rccl_one_rank_worker(rank, world, port, q):
     try:

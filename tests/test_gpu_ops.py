@@ -704,3 +704,27 @@ def test_narrow_entry_points_reject_bad_arguments():
     with pytest.raises(RuntimeError):      # valid > padded
         LIB.call("uh_conv3x3_fwd_narrow", x.data_ptr(), 64, 128, 16, None, 0, 0, 0, w.data_ptr(), y.data_ptr(), 16, 64, 16,
                  None, None, None, 1, 8, 8, UH_BF16, st)
+
+
+def test_default_library_refuses_the_consumer_side_batchnorm_calls_loudly():
+    """The PRE instantiations (BatchNorm + ReLU applied by the consumer conv's loaders: built, measured a net loss) live behind the
+    build flag UH_BUILD_PRE=1.  The default library must say so -- uh_conv3x3_pre_ok answers 0 and both entry points fail with a
+    message that names the flag -- and never run something else instead."""
+    from unet_amd._lib import LIB, UH_BF16
+    dev = _dev()
+    if LIB.query("uh_conv3x3_pre_ok", 2, 64, 64, 128, 256, 128, 256, UH_BF16):
+        pytest.skip("this library was built with UH_BUILD_PRE=1")
+    x = torch.zeros(2, 64, 64, 128, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(2, 64, 64, 256, dtype=torch.bfloat16, device=dev)
+    c = torch.zeros(256, device=dev)
+    w = torch.zeros(256 * 9 * 128, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(RuntimeError, match="UH_BUILD_PRE"):
+        LIB.call("uh_conv3x3_fwd_pre", x.data_ptr(), 128, 128, c.data_ptr(), c[128:].data_ptr(), w.data_ptr(), y.data_ptr(), 256, 256,
+                 None, 2, 64, 64, UH_BF16, st)
+    dw = torch.zeros(256 * 9 * 128, device=dev)
+    nbytes = LIB.query("uh_conv3x3_wgrad_ws_bytes", 2, 64, 64, 128, 256, UH_BF16)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="UH_BUILD_PRE"):
+        LIB.call("uh_conv3x3_wgrad_pre", y.data_ptr(), 256, x.data_ptr(), 128, 128, c.data_ptr(), c[128:].data_ptr(), dw.data_ptr(), 256,
+                 ws.data_ptr(), nbytes, 2, 64, 64, UH_BF16, st)

@@ -598,9 +598,12 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     constexpr int NPIECE = HALO_PIX * 4;     // 1296
     constexpr int NLOAD = 6;
 #ifndef UH_FWD_PF
-#define UH_FWD_PF 1
+#define UH_FWD_PF 2
 #endif
-    constexpr int PF = UH_FWD_PF;            // LDS fragment prefetch distance in halo rows
+    // LDS fragment prefetch distance in halo rows.  Two rows ahead (192 cycles of MFMA issue at NBW = 2 instead of 96): +0.3 % on
+    // the train step in three interleaved rounds (856.5 -> 858.9 images/s, round 4); the register-resident-filter form has no four
+    // registers to spare for it (it spills inside its MFMA stream at distance 2) and keeps one row.
+    constexpr int PF = WRES ? 1 : UH_FWD_PF;
 
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * HALO2_STRIDE];
     // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
@@ -2106,6 +2109,7 @@ extern "C" int uh_conv3x3_fwd_pre(const void* x0, int C0, int ld0, const float* 
     const bool wfrag = (dt & UH_WFRAG) != 0;
     dt &= ~UH_WFRAG;
     UH_REQUIRE(dt == UH_BF16, "uh_conv3x3_fwd_pre: bf16 only (dtype %d)", dt);
+    UH_REQUIRE(UH_BUILD_PRE, "uh_conv3x3_fwd_pre: the consumer-side BatchNorm+ReLU instantiations are not in this build (UH_BUILD_PRE=1); uh_conv3x3_pre_ok says so");
     UH_REQUIRE(uh_conv3x3_pre_ok(B, H, W, C0, Cout, ld0, ldy, dt), "uh_conv3x3_fwd_pre: shape outside the fused path (uh_conv3x3_pre_ok)");
     bool done;
     return conv3x3_fwd_dispatch<bf16_t>((const bf16_t*)x0, C0, ld0, nullptr, 0, 0, (const bf16_t*)w, (bf16_t*)y, ldy, Cout,

@@ -90,6 +90,7 @@ class BucketedGradSync:
 
     def reset(self):
         self.pending = list(self.members)
+        self.next_launch = 0                             # buckets are launched strictly in index order (see mark_ready)
         self.launched = [False] * len(self.buckets)
         self.side_event = [None] * len(self.buckets)     # latest side-stream event among a bucket's gradients
         self.handles = []
@@ -127,13 +128,19 @@ class BucketedGradSync:
         if event is not None:
             self.side_event[b] = event
         self.pending[b] -= 1
-        if self.pending[b] == 0:
-            self._launch(b)
+        # Strictly in index order: every rank issues the SAME sequence of collectives whatever order its gradients arrive in --
+        # a parameter that gets no gradient on one rank only (its slice is marked ready at the optimizer step) delays the
+        # buckets behind it on that rank instead of re-ordering them against its peers' (mis-ordered collectives hang RCCL).
+        # Gradients arrive in flat order (backward-ready order IS the bucket order), so this costs no overlap.
+        while self.next_launch < len(self.buckets) and self.pending[self.next_launch] == 0:
+            self._launch(self.next_launch)
+            self.next_launch += 1
 
     def wait(self):
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
+        self.next_launch = len(self.buckets)
         timed = self.time_exposed and self.flat.is_cuda and self.active
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)

@@ -213,8 +213,6 @@ class FusedRMSprop:
         stale = [i for i, f in enumerate(self._fresh) if not f]
         if stale and len(stale) == len(self._fresh):
             raise RuntimeError("FusedRMSprop.step() without a backward pass since the last step / zero_grad")
-        if self.sync is not None:
-            self._check_stale_pattern()
         runs = [(0, self.total)]
         if stale:
             for i in stale:
@@ -234,6 +232,10 @@ class FusedRMSprop:
                     start = None
             if start is not None:
                 runs.append((start, last - start))
+        if self.sync is not None:
+            # (behind the stale slices' mark_ready: every bucket has been issued -- in index order on every rank -- so the
+            # comparison's own all-reduce sits at the same place in every rank's sequence of collectives)
+            self._check_stale_pattern()
         self._fresh = [False] * len(self.params)
         if self.sync is not None:
             self.sync.wait()
