@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs (a rank waiting at a collective, a kernel that never ends) must FAIL with its name, not leave the whole
+    run silent until the GPU box's watchdog (420 s without output) kills it: a per-test limit below that, where pytest-timeout
+    is installed (the slowest legitimate test, the two-rank config-5 rehearsal, takes about a minute)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(390))
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 

@@ -66,7 +66,7 @@ def test_two_ranks_share_one_gpu_over_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]   # (below the GPU box's 420 s silence limit: a hung rank fails the test instead of the run)
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
@@ -126,7 +126,7 @@ def test_sync_bn_data_parallel_equals_single_process(cuts):
     procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]   # (below the GPU box's 420 s silence limit: a hung rank fails the test instead of the run)
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
@@ -154,16 +154,22 @@ def test_sync_bn_data_parallel_equals_single_process(cuts):
 
 
 # ------------------------------------------------------------------------------------------ the untested DP pieces
-def _spawn(target, *extra, world=2, timeout=600):
+def _spawn(target, *extra, world=2, timeout=300):       # (below the GPU box's 420 s silence limit)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=timeout) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        res = [q.get(timeout=timeout) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:               # a rank that hangs must not outlive the test (it holds the GPU)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
     assert all(r[1] == "ok" for r in res), res
     return sorted(res)
 
@@ -333,7 +339,9 @@ def _stale_pattern_worker(rank, world, port, q, mode):
                 break
         torch.cuda.synchronize()
         q.put((rank, "ok", err))
-        os._exit(0)          # (a bucket all-reduce may still be pending on the rank that saw every gradient: do not wait for it)
+        q.close()
+        q.join_thread()      # (the queue's feeder thread must have flushed the item before the process goes away)
+        os._exit(0)          # (skip the interpreter's teardown: nothing here may wait for a collective a peer will never join)
     except Exception:  # pragma: no cover
         import traceback
         q.put((rank, traceback.format_exc()))

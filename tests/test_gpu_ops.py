@@ -443,7 +443,7 @@ def test_batched_weight_pack_matches_per_layer(dtype):
     from unet_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(4)
-    shapes = [(64, 1), (64, 64), (128, 64), (16, 24), (8, 3), (256, 128)]
+    shapes = [(64, 1), (64, 64), (128, 64), (16, 24), (8, 3), (256, 128), (128, 512), (512, 1024), (72, 40), (96, 160)]      # odd entries channels_last: whole 32 x 32 tiles take the 16-byte form, (96, 160) mixes both forms
     ws = []
     for k, (o, i) in enumerate(shapes):
         w = torch.randn(o, i, 3, 3, generator=g).to(dev)
