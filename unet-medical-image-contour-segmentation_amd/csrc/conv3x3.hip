@@ -2525,6 +2525,36 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     slab_reduce_block_f32(slabs, out, n, nsplit, blockIdx.x, red);
 }
 
+// Many splits of a SMALL result (the recomputed stem: 1024 slabs of 576 floats): the form above would run three blocks whose
+// threads each walk 256 slabs (24 us).  Here a block is 4 float4 columns x 64 split lanes: 16 slabs per thread, four loads in
+// flight, the 16 split lanes of a wave by shuffles and the four waves through LDS -- a fixed order again.
+__global__ __launch_bounds__(256) void slab_reduce_tall_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
+                                                               int nsplit) {
+    __shared__ f32x4 red[4][4];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+    const int64_t n4 = n >> 2;
+    const int64_t i4 = (int64_t)blockIdx.x * 4 + cl;
+    const int64_t ic = i4 < n4 ? i4 : n4 - 1;
+    const f32x4* base = reinterpret_cast<const f32x4*>(slabs) + ic;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int k = sl;
+    for (; k + 192 < nsplit; k += 256) {
+        a0 += base[(int64_t)k * n4];
+        a1 += base[(int64_t)(k + 64) * n4];
+        a2 += base[(int64_t)(k + 128) * n4];
+        a3 += base[(int64_t)(k + 192) * n4];
+    }
+    for (; k < nsplit; k += 64) a0 += base[(int64_t)k * n4];
+    f32x4 v = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+    if ((threadIdx.x & 63) < 4) red[wave][cl] = v;
+    __syncthreads();
+    if (threadIdx.x < 4 && i4 < n4) reinterpret_cast<f32x4*>(out)[i4] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 // The same for slabs of bf16 pairs (conv3x3_wgrad_mfma_v2<.., SLAB16>): dword (cp, tap, ci) of a slab = rows 2 cp, 2 cp + 1 of one
 // (tap, ci).  npair = (Cout / 2) * row dwords per slab, row = 9 * Cin (a multiple of 4: a 16-byte piece stays inside one row pair).
 __device__ __forceinline__ void slab_reduce_block_bf16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
@@ -3638,6 +3668,8 @@ extern "C" int uh_stem_bn_relu_bwd_wgrad(const void* dz, int lddz, const void* x
     const int nsplit = uh_stem_nblk(B, H, W);
     if (n % 4 != 0 || !uh_aligned16(dw_krsc) || !uh_aligned16(slabs))
         hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)slabs, dw_krsc, n, nsplit);
+    else if (n <= 4096 && nsplit >= 256)
+        hipLaunchKernelGGL(slab_reduce_tall_kernel, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, st, (const float*)slabs, dw_krsc, n, nsplit);
     else
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, st, (const float*)slabs, dw_krsc, n, nsplit);
     UH_CHECK_LAUNCH("slab_reduce_kernel");
