@@ -728,3 +728,27 @@ def test_default_library_refuses_the_consumer_side_batchnorm_calls_loudly():
     with pytest.raises(RuntimeError, match="UH_BUILD_PRE"):
         LIB.call("uh_conv3x3_wgrad_pre", y.data_ptr(), 256, x.data_ptr(), 128, 128, c.data_ptr(), c[128:].data_ptr(), dw.data_ptr(), 256,
                  ws.data_ptr(), nbytes, 2, 64, 64, UH_BF16, st)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 128, 128, 128, 256), (2, 256, 256, 64, 64), (4, 32, 32, 512, 512)])
+def test_bf16_slabs_are_no_less_precise_than_the_reference_rounding_of_the_total(B, H, W, Cin, Cout):
+    """The per-split partial sums of bf16 backward-weights travel to the reduce kernel as bf16 pairs (SLAB16) and are added in fp32.
+    The reference's autocast backward returns the filter gradient in bf16, i.e. it rounds the TOTAL (train.py:116; the conv's weight
+    is a bf16 copy).  Claim held here: against fp64, the error of this kernel's fp32 result is of the size of that single rounding
+    of the total (rms over the tensor, not above 1.25 x), and far below bf16's own step on the largest elements."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g)).bfloat16().float()           # activations as the layer sees them: half zeros
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    xd = x.double()
+    wd = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (dwref,) = torch.autograd.grad(F.conv2d(xd, wd, padding=1), [wd], dy.double())
+    dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
+    ops.conv3x3_wgrad(_nhwc(dy, torch.bfloat16, dev), _nhwc(x, torch.bfloat16, dev), None, dwk)
+    ours = dwk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu()
+    as_reference = dwref.float().bfloat16().double()                                       # what autocast hands to the optimizer
+    e_ours = float((ours - dwref).pow(2).mean().sqrt())
+    e_ref = float((as_reference - dwref).pow(2).mean().sqrt())
+    assert e_ours <= 1.25 * e_ref, (e_ours, e_ref)
+    assert float((ours - dwref).abs().max()) <= 3e-3 * float(dwref.abs().max())
