@@ -175,9 +175,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 // the horizontal results -- which two is uniform over the workgroup, so it is a scalar branch, not a per-lane select.
 // PRE: x is the RAW output of a conv and the activation that is up-sampled, max(x * scale + shift, 0) rounded to T exactly as
 // uh_bn_relu_apply would have stored it, is formed on the way in (uh_bn_relu_upsample2x_fwd: that activation has no other reader).
-// Output rows per thread.  Eight rows (six input rows instead of two groups of four, a quarter fewer loads and BatchNorm + ReLU +
-// rounding operations per stored value) measured no different from four on the four Up-block shapes of config 2 (round 4,
-// scratch/r4_upbench.py: 188.3 vs 188.6 us in all, 3.2-3.9 TB/s of tensor bytes): the kernel is not waiting for its VALU work.
+// Output rows per thread.  The kernel is VALU-bound: SQ counters over the four Up-block shapes of config 2 (round 4, scratch/r4_up_pmc.sh)
+// give 748 VALU instructions per thread (four 16-byte stores) = 47.9 k per SIMD on the 512 x 512 x 64 output, x 4 cycles = the whole
+// 96 us launch.  Unpacking bf16, BatchNorm + ReLU + rounding of every LOADED value (the PRE form) and the two interpolation stages
+// are what the arithmetic is; ~130 of the 748 are register copies / selects of the row picks and the zero-padding tests.  Eight
+// rows per thread (six input rows instead of two groups of four: a quarter fewer loads) measured no different (188.3 vs 188.6 us
+// over the four shapes): the longer pick chains cost what the loads save.
 constexpr int UP_ROWS = 4;
 template <typename T, int V, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
