@@ -9,7 +9,7 @@ LAYERS = [("inc.3", 512, 64, 64), ("down1.0", 256, 64, 128), ("down1.3", 256, 12
           ("down3.0", 64, 256, 512), ("down3.3", 64, 512, 512), ("down4.0", 32, 512, 512), ("down4.3", 32, 512, 512),
           ("up1.0", 64, 1024, 512), ("up1.3", 64, 512, 256), ("up2.0", 128, 512, 256), ("up2.3", 128, 256, 128),
           ("up3.0", 256, 256, 128), ("up3.3", 256, 128, 64), ("up4.0", 512, 128, 64), ("up4.3", 512, 64, 64)]
-B = 8
+B = 8                                  # sixth argument overrides (the batch-4 leg)
 
 
 def is_bnsum(name: str) -> bool:
@@ -26,7 +26,10 @@ def is_bnsum(name: str) -> bool:
 
 
 def main():
+    global B
     trace, nsteps, out, note = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    if len(sys.argv) > 5:
+        B = int(sys.argv[5])
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
     fam = [r for r in rows if "conv3x3_fwd_mfma_v2" in r["Kernel_Name"]]
     wg = [r for r in rows if "conv3x3_wgrad_mfma_v2" in r["Kernel_Name"]]

@@ -640,7 +640,15 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     // registers to spare for it (it spills inside its MFMA stream at distance 2) and keeps one row.
     constexpr int PF = WRES ? 1 : UH_FWD_PF;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * HALO2_STRIDE];
+#ifndef UH_WRES_TRI
+#define UH_WRES_TRI 1
+#endif
+    // TRI (the register-resident-filter form): THREE halo buffers, the DMA runs two chunks = one whole tile ahead.  With 16 channels
+    // per wave a chunk is 144 MFMAs, and the two column shifts a double-buffered DMA has to land under (96 MFMAs, ~1 us beside the
+    // SIMD's other wave) are shorter than an HBM round trip under load: the 64 -> 64 layers at 512 x 512 waited at every chunk fence
+    // (scratch/r4_bsum_bench.sh with the cached-input variant: 141 -> 115 us per launch).  72 KB per workgroup, two per CU.
+    constexpr bool TRI = WRES && !PRE && UH_WRES_TRI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[(TRI ? 3 : KS * 2) * HALO2_STRIDE];
     // BatchNorm statistics of this workgroup's channels over ALL the tiles it processes, as pivot-shifted sums
     // S1 = sum (v - p), S2 = sum (v - p)^2 with p = one stored value of the channel (so that |mean - p| ~ std and the
     // final M2 = S2 - S1^2 / n does not cancel): one partial row per WORKGROUP (<= 768 rows), written once at the end.
@@ -871,7 +879,10 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     // end of a chunk: the next buffer's DMA (and the asynchronous filter loads) have landed, every wave is done reading the
     // current buffer.  PRE: the wave's own pieces are rewritten between its vmcnt(0) and the barrier.
     auto chunk_fence = [&](int c_next, int bufi_next, bool live_next) {
-        if constexpr (PRE) {
+        if constexpr (TRI) {
+            // the six pieces of the chunk AFTER the next one stay in flight (vmcnt retires in order: everything older has landed)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NLOAD) : "memory");
+        } else if constexpr (PRE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (live_next) pre_transform(c_next, bufi_next);
@@ -976,6 +987,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
                     wres[c][t][n].v = u32x4{0u, 0u, 0u, 0u};
                     wfrag_async(wres[c][t][n], (int64_t)c * CK + n * wnb_stride + (int64_t)t * Cin, n, t, c);
                 }
+        if constexpr (TRI) dma_chunk(1, 1, true);      // (behind the filter: the first fence leaves exactly these six in flight)
     } else {
         load_w(wA, chunk_of(v_first), 0);
     }
@@ -1004,12 +1016,20 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
 
         if constexpr (WRES) {
             // two chunks, filter in registers: the only vector-memory traffic is the halo DMA of what follows
+            bool live_next = true;
 #pragma unroll
-            for (int v = 0; v < 2; ++v, bufi ^= 1) {
+            for (int v = 0; v < 2; ++v) {
                 const unsigned char* buf = lds + bufi * HALO2_STRIDE;
                 mma_shift(buf, 0, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 0][n]; });
-                bool live_next = true;
-                if (v == 0) {
+                if constexpr (TRI) {
+                    // chunk v of the NEXT tile, into the buffer the chunk in front of this one was read from
+                    const int b2 = bufi == 0 ? 2 : bufi - 1;
+                    if (v == 0) {
+                        live_next = next_tile < ntile;
+                        if (live_next) dma_tile(next_tile);
+                    }
+                    dma_chunk(v, b2, live_next);
+                } else if (v == 0) {
                     dma_chunk(1, bufi ^ 1, true);
                 } else {
                     live_next = next_tile < ntile;
@@ -1019,7 +1039,8 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
                 __builtin_amdgcn_sched_barrier(0);
                 mma_shift(buf, 1, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 1][n]; });
                 mma_shift(buf, 2, [&](int r, int n) -> const WFrag& { return wres[v][r * 3 + 2][n]; });
-                chunk_fence(v == 0 ? 1 : 0, bufi ^ 1, live_next);
+                chunk_fence(v == 0 ? 1 : 0, TRI ? 0 : (bufi ^ 1), live_next);
+                if constexpr (TRI) bufi = bufi == 2 ? 0 : bufi + 1; else bufi ^= 1;
             }
         } else {
 #pragma unroll 1
