@@ -54,7 +54,15 @@ for name, H, Cin, Cout in LAYERS:
         t = timeit(run)
         tot[kind] += t
         mb = (B * H * W * (ci + co) * 2) / 1e6
-        line += f" | {kind} {t:7.1f} us {gf / t * 1e3:5.0f} TF ({mb / t * 1e-6 * 1e6 / 1e3:4.1f} TB/s alg)"
+        line += f" | {kind} {t:7.1f} us {gf / t * 1e3:5.0f} TF"
         del x, y, w, wf
+    # backward-weights (the MFMA kernel + its slab reduction)
+    dyt = (torch.randn(B, H, W, Cout, device=dev) * 0.1).bfloat16()
+    xt = (torch.randn(B, H, W, Cin, device=dev) * 0.5).bfloat16()
+    dw = torch.empty(Cout, 3, 3, Cin, dtype=torch.float32, device=dev)
+    t = timeit(lambda: ops.conv3x3_wgrad(dyt, xt, None, dw))
+    tot["wgrad"] = tot.get("wgrad", 0.0) + t
+    line += f" | wgrad+reduce {t:7.1f} us {gf / t * 1e3:5.0f} TF"
+    del dyt, xt, dw
     print(line, flush=True)
-print(f"sum fwd {tot['fwd']:.1f} us, dgrad {tot['dgrad']:.1f} us")
+print(f"sum fwd {tot['fwd']:.1f} us, dgrad {tot['dgrad']:.1f} us, wgrad+reduce {tot['wgrad']:.1f} us")
