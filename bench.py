@@ -71,8 +71,9 @@ def parse():
                     "the multi-rank flow on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--side-stream", action="store_true",
-                    help="backward-weights kernels on a stream of their own (measured 2-3 %% slower than one stream: DESIGN.md)")
-    ap.add_argument("--no-side-stream", action="store_true", help="(the default since round 2; accepted for old command lines)")
+                    help="force backward-weights onto a stream of its own (default: TrainStepper decides per step -- on for bf16 steps "
+                         "of >= 2^20 pixels per process: +1.5 %% at batch 8, DESIGN.md)")
+    ap.add_argument("--no-side-stream", action="store_true", help="force one stream (A/B runs)")
     return ap.parse_args()
 
 
@@ -318,7 +319,7 @@ def main():
                                                check_nan=os.environ.get("UH_GRAPH_NO_NAN_CHECK") != "1")
         args.no_kernel_profile = True          # per-launch events cannot be recorded inside a replayed graph
     else:
-        stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=args.side_stream and not args.no_side_stream, cc_loss=args.cc_loss,
+        stepper = unet_amd.TrainStepper(model, lr=1e-5, amp=amp, wgrad_stream=(False if args.no_side_stream else (True if args.side_stream else None)), cc_loss=args.cc_loss,
                                        fp32_mode="bf16x3" if (args.fp32 and args.bf16x3) else "exact", sync_bn=args.sync_bn)
     strong = args.global_batch > 0
     if strong:
@@ -570,7 +571,8 @@ def main():
                        "baseline_config": baseline_config(args, world, B, amp, bilinear),
                        "parallelism": f"dp{world}", "global_batch": B * world, "per_gpu_batch": B,
                        "bn": "global-batch statistics (SyncBN)" if args.sync_bn else "per-rank batch statistics",
-                       "dice": "global-batch sums (all-reduced)"},
+                       "dice": "global-batch sums (all-reduced)",
+                       "streams": ("backward-weights on a side stream" if stepper._side_for(images) is not None else "one stream")},
             "loss": round(loss, 6),
             "train_tflops_per_gpu": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3, 1),
             "conv_roofline_frac_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE[bilinear] / 1e3 /

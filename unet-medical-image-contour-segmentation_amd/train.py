@@ -372,14 +372,23 @@ class TrainStepper:
 
     def __init__(self, model: nn.Module, lr: float = 1e-5, weight_decay: float = 1e-8, momentum: float = 0.999,
                  gradient_clipping: float = 1.0, amp: bool = True, process_group=None, check_nan: bool = True,
-                 wgrad_stream: bool = False, cc_loss: bool = False, sync_bn: bool = False, fp32_mode: str = "exact"):
+                 wgrad_stream: Optional[bool] = None, cc_loss: bool = False, sync_bn: bool = False, fp32_mode: str = "exact"):
         self.model = model
-        # wgrad_stream: backward-weights kernels on a stream of their own.  Off by default: a kernel trace shows them
-        # overlapping with the BatchNorm / backward-data kernels of the launch stream as intended, and every kernel of
-        # the pair then runs about as much slower as the overlap saves (the chip is at its power limit either way) --
-        # the step is 2-3 % FASTER on one stream (DESIGN.md "Measured (round 2)").
+        # wgrad_stream: backward-weights kernels (and their slab reductions) on a stream of their own, beside the BatchNorm /
+        # pool / upsample backward kernels of the layers that follow.  True / False force it; None (default) decides per step
+        # (`_side_for`): ON for bf16 steps of at least 2^20 pixels per process.  Round 2 measured one stream 2-3 % faster and
+        # turned it off; with round 4's kernels (bf16 slabs, rotated backward-weights loop) it is the other way round on the
+        # GPU-bound bf16 configurations -- batch 8: 872.2 -> 884.9 images/s (+1.5 %), batch 4 +2.2 %, batch 32 +1 %, config 4
+        # +1.1 %, transposed-conv variant +0.8 %, three interleaved rounds each -- while exact fp32 loses 3 % and batch 2
+        # (host-bound: two more stream switches per layer) 7-20 % (DESIGN.md "Measured (round 4)").  UH_SIDE_STREAM=0 / 1
+        # overrides the automatic choice.
         # (kept on the instance and installed for the duration of step(): another live stepper keeps its own choice)
-        self.wgrad_stream = torch.cuda.Stream() if wgrad_stream else None
+        self._side_auto = wgrad_stream is None
+        env = os.environ.get("UH_SIDE_STREAM")
+        if self._side_auto and env in ("0", "1"):
+            wgrad_stream, self._side_auto = (env == "1"), False
+        want = wgrad_stream is None or bool(wgrad_stream)
+        self.wgrad_stream = torch.cuda.Stream() if (want and torch.cuda.is_available()) else None
         self.amp = amp
         self.check_nan = check_nan
         if fp32_mode not in ("exact", "bf16x3"):
@@ -438,12 +447,22 @@ class TrainStepper:
         except Exception:
             pass
 
+    SIDE_MIN_PIXELS = 1 << 20
+
+    def _side_for(self, images):
+        """The stream backward-weights runs on in the step over `images` (None: the launch stream)."""
+        if self.wgrad_stream is None or not self._side_auto:
+            return self.wgrad_stream
+        big = images.is_cuda and images.shape[0] * images.shape[-2] * images.shape[-1] >= self.SIDE_MIN_PIXELS
+        return self.wgrad_stream if (self.amp and big) else None
+
     def step(self, images, true_masks, global_batch: Optional[int] = None):
         """One optimizer step (train.py:113-159).  `global_batch` (data parallel with sync_bn): the sum of the ranks' batch
         sizes when the caller knows it (equal shards: world * B) -- otherwise it is all-reduced here, which costs a blocking
         host read per step."""
         self.model.train()
-        ops.WGRAD_STREAM = self.wgrad_stream
+        side = self._side_for(images)
+        ops.WGRAD_STREAM = side
         ops.SYNC_BN = self.sync_bn
         ops.SYNC_BN_BATCH = None
         world = self.world
@@ -462,7 +481,7 @@ class TrainStepper:
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
         self._slabs.reset()
-        ops.SLAB_BATCH = self._slabs if self.wgrad_stream is None else None
+        ops.SLAB_BATCH = self._slabs if side is None else None
         try:
             return train_step(self.model, self.optimizer, images, true_masks, amp=self.amp,
                               reduce_sums=self.reduce_sums, world=world, check_nan=self.check_nan, cc_loss=self.cc_loss)
@@ -477,6 +496,7 @@ class GraphedTrainStepper(TrainStepper):
     only.  A NaN loss is detected after the replay (the fused optimizer kernel has skipped the update: non-finite norm)."""
 
     def __init__(self, model: nn.Module, *args, warmup: int = 2, **kw):
+        kw.setdefault("wgrad_stream", False)         # one stream unless asked for: the graph is for launch-bound small models
         super().__init__(model, *args, **kw)
         if self.world != 1:
             raise RuntimeError("GraphedTrainStepper is single-process; use TrainStepper with torch.distributed")
@@ -488,7 +508,8 @@ class GraphedTrainStepper(TrainStepper):
 
     def _eager_step(self, images, masks):
         self.model.train()
-        ops.WGRAD_STREAM = self.wgrad_stream
+        side = self._side_for(images)
+        ops.WGRAD_STREAM = side
         ops.SYNC_BN = None
         ops.FP32_MODE = self.fp32_mode
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
@@ -499,7 +520,7 @@ class GraphedTrainStepper(TrainStepper):
             ops.WEIGHT_PACK = self._pack
             self._pack.refresh()
         self._slabs.reset()
-        ops.SLAB_BATCH = self._slabs if self.wgrad_stream is None else None
+        ops.SLAB_BATCH = self._slabs if side is None else None
         try:
             return train_step(self.model, self.optimizer, images, masks, amp=self.amp, reduce_sums=self.reduce_sums,
                               world=self.world, check_nan=False)
