@@ -388,7 +388,9 @@ class TrainStepper:
         if self._side_auto and env in ("0", "1"):
             wgrad_stream, self._side_auto = (env == "1"), False
         want = wgrad_stream is None or bool(wgrad_stream)
-        self.wgrad_stream = torch.cuda.Stream() if (want and torch.cuda.is_available()) else None
+        # (a high-priority stream: 897.6 vs 894.9 images/s on the default priority, 893.2 on a low one, 884.8 on one stream --
+        # scratch/r4_prio_probe.py, three interleaved rounds)
+        self.wgrad_stream = torch.cuda.Stream(priority=-1) if (want and torch.cuda.is_available()) else None
         self.amp = amp
         self.check_nan = check_nan
         if fp32_mode not in ("exact", "bf16x3"):
