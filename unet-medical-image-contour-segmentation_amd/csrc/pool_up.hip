@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 // Output rows per thread.  The kernel is VALU-bound: SQ counters over the four Up-block shapes of config 2 (round 4, scratch/r4_up_pmc.sh)
 // give 748 VALU instructions per thread (four 16-byte stores) = 47.9 k per SIMD on the 512 x 512 x 64 output, x 4 cycles = the whole
 // 96 us launch.  Unpacking bf16, BatchNorm + ReLU + rounding of every LOADED value (the PRE form) and the two interpolation stages
-// are what the arithmetic is; ~130 of the 748 are register copies / selects of the row picks and the zero-padding tests.  Eight
+// are what the arithmetic is; ~130 of the 748 were register copies / selects of the row picks and the zero-padding tests -- gone since
+// the vertical blend reads the two rows where they are (one scalar branch per (a, bb) pair) and padding columns carry zeros through
+// it: 188.6 -> 164.3 us over the four Up-block shapes of config 2, bit-identical.  Eight
 // rows per thread (six input rows instead of two groups of four: a quarter fewer loads) measured no different (188.3 vs 188.6 us
 // over the four shapes): the longer pick chains cost what the loads save.
 constexpr int UP_ROWS = 4;
@@ -212,6 +214,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
     // R output rows advance the source row by < (R - 1) / 2, so they touch input rows base .. base + R / 2 + 1 at most
     constexpr int NR = R / 2 + 2;
     float hr[NR][V];                                   // horizontally interpolated input rows base .. base + NR - 1
+    // (columns in the zero padding keep zeros here: the vertical stage then needs no per-lane test -- 0 * l + 0 * l is the 0 F.pad
+    // writes, whatever the neighbours hold)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int i = 0; i < V; ++i) hr[j][i] = 0.f;
     if (col_in) {
         const UpCoord cx = up_coord(ux, sx, w);
         float sc[PRE ? V : 1], sh[PRE ? V : 1];
@@ -243,18 +251,23 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
         float o[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) o[i] = 0.f;
-        if (row_in[r] && col_in) {
-            const int a = cy[r].i0 - base, bb = cy[r].i1 - base;      // in 0..3, uniform over the workgroup: scalar branches
+        if (row_in[r]) {
+            // a, bb (<= a + 1) are uniform over the workgroup: one scalar branch per (a, bb) pair, the blend reads the two rows where
+            // they are (copying them into a pair of row registers first cost sixteen moves per output row)
+            const int a = min(cy[r].i0 - base, NR - 1), bb = min(cy[r].i1 - base, NR - 1);
             const float l0 = cy[r].l0, l1 = cy[r].l1;
-            float ra[V], rb[V];
-            auto pick = [&](int k, float (&dst)[V]) {              // k is uniform over the workgroup: a chain of scalar branches
-                _Pragma("unroll") for (int j = 0; j < NR; ++j)
-                    if (k == j || (j == NR - 1 && k >= NR)) { _Pragma("unroll") for (int i = 0; i < V; ++i) dst[i] = hr[j][i]; }
+            auto blend = [&](const float (&ra)[V], const float (&rb)[V]) {
+                _Pragma("unroll") for (int i = 0; i < V; ++i) o[i] = fmaf(l0, ra[i], __fmul_rn(l1, rb[i]));
             };
-            pick(a, ra);
-            pick(bb, rb);
+            bool done = false;
 #pragma unroll
-            for (int i = 0; i < V; ++i) o[i] = fmaf(l0, ra[i], __fmul_rn(l1, rb[i]));
+            for (int j = 0; j < NR; ++j) {
+                if (!done && a == j) {
+                    if (bb == j || j == NR - 1) blend(hr[j], hr[j]);
+                    else blend(hr[j], hr[j + 1 < NR ? j + 1 : j]);
+                    done = true;
+                }
+            }
         }
         uh_store<T, V>(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c, o);
     }
