@@ -357,11 +357,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 // weights come from the forward's own up_coord, so this is the exact transpose) and adds l0*t / l1*t to the two input
 // rows i0(uy), i0(uy)+1 it feeds.  i0 is non-decreasing in uy, so two running accumulators suffice and every input
 // row is stored exactly once.  ~2.3 gathered 16-byte loads per stored element instead of the full window scan.
-template <typename T, int V>
+// BUF (tensors below 1 GiB): dy is read through a buffer descriptor with 32-bit offsets = column part + row part.  A column that
+// carries no weight for this thread has the column part 2^30 and a row outside the strip's range the row part 2^31: the sum is
+// out of range (no wrap: 2^30 + 2^31 < 2^32) and the load returns zeros -- so nothing has to be selected away behind the loads
+// (the pointer form clamps such loads to a valid address and replaces what they return: 48 selects per output row in a kernel
+// that SQ counters show VALU-bound, scratch/r4_up_pmc.sh) and no 64-bit address arithmetic is left in the row loop.
+template <typename T, int V, bool BUF = false>
 __global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx,
                                                                    int lddx, int B, int h, int w, int C, int Ho, int Wo,
-                                                                   int pt, int pl, float sy, float sx, int ty) {
+                                                                   int pt, int pl, float sy, float sx, int ty, unsigned dy_bytes = 0) {
     constexpr int NC = 6;
+    constexpr int ES = (int)sizeof(T);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
     const int G = C / V;
     const int nstrip = (h + ty - 1) / ty;
     const int64_t total = (int64_t)B * nstrip * w * G;
@@ -393,21 +400,49 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip_kernel(const T* __re
         // every load goes to a valid address (row and column clamped to ones this thread does use) and a value that
         // must not count is replaced by 0 AFTER the load -- so the loads of two rows (<= 12) are all in flight before the
         // first one is consumed, and a NaN in a pixel this input does not depend on cannot leak in through a zero weight.
+        unsigned colpart[BUF ? NC : 1];
+        if constexpr (BUF) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) colpart[k] = wxs[k] != 0.f ? (unsigned)(((uxb + pl + k) * lddy + c) * ES) : 0x40000000u;
+        }
         auto row_sum = [&](int uy, float (&tt)[V]) {
             const int oy = uy + pt;
             const bool live = uy <= uy_hi && oy >= 0 && oy < Ho;
-            const int oyc = min(max(oy, 0), Ho - 1);
-            const T* row = dy + ((int64_t)(b * Ho + oyc) * Wo + uxb + pl) * lddy + c;
             float g[NC][V];
+            if constexpr (BUF) {
+                const unsigned rowpart = live ? (unsigned)((b * Ho + oy) * Wo * lddy * ES) : 0x80000000u;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) uh_load<T, V>(row + (int64_t)(wxs[k] != 0.f ? k : kval) * lddy, g[k]);
+                for (int k = 0; k < NC; ++k) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsd, colpart[k] + rowpart, 0, 0);
+                    if constexpr (ES == 2) {
+                        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
-            for (int i = 0; i < V; ++i) tt[i] = 0.f;
+                        for (int i = 0; i < V; ++i) g[k][i] = (float)v[i];
+                    } else {
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                const bool use = live && wxs[k] != 0.f;
+                        for (int i = 0; i < V; ++i) g[k][i] = __uint_as_float(raw[i]);
+                    }
+                }
 #pragma unroll
-                for (int i = 0; i < V; ++i) tt[i] = use ? fmaf(wxs[k], g[k][i], tt[i]) : tt[i];
+                for (int i = 0; i < V; ++i) tt[i] = 0.f;
+                // (a zero weight meets a zero: fma(0, 0, t) = t exactly -- t starts at +0 and +0 + -0 = +0, so no sign of zero changes)
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) tt[i] = fmaf(wxs[k], g[k][i], tt[i]);
+            } else {
+                const int oyc = min(max(oy, 0), Ho - 1);
+                const T* row = dy + ((int64_t)(b * Ho + oyc) * Wo + uxb + pl) * lddy + c;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) uh_load<T, V>(row + (int64_t)(wxs[k] != 0.f ? k : kval) * lddy, g[k]);
+#pragma unroll
+                for (int i = 0; i < V; ++i) tt[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const bool use = live && wxs[k] != 0.f;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) tt[i] = use ? fmaf(wxs[k], g[k][i], tt[i]) : tt[i];
+                }
             }
         };
         // row pass: fold the column sums of output row uy into the two running input-row accumulators
@@ -520,8 +555,13 @@ extern "C" int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
             int ty = 16;
             while (ty > 2 && (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC) < 256 * 1024) ty >>= 1;
             const int64_t nthr = (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC);
-            hipLaunchKernelGGL((upsample2x_bwd_strip_kernel<T, VEC>), dim3(pu_grid(nthr)), dim3(256), 0, st, (const T*)dy,
-                               lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, ty);
+            const int64_t dyb = (int64_t)B * Ho * Wo * lddy * (int64_t)sizeof(T);
+            if (dyb < (1ll << 30))
+                hipLaunchKernelGGL((upsample2x_bwd_strip_kernel<T, VEC, true>), dim3(pu_grid(nthr)), dim3(256), 0, st, (const T*)dy,
+                                   lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, ty, (unsigned)dyb);
+            else
+                hipLaunchKernelGGL((upsample2x_bwd_strip_kernel<T, VEC>), dim3(pu_grid(nthr)), dim3(256), 0, st, (const T*)dy,
+                                   lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, ty);
         } else if (uh_vec_ok<T>(dy, lddy, C) && uh_vec_ok<T>(dx, lddx, C))
             hipLaunchKernelGGL((upsample2x_bwd_kernel<T, VEC>), dim3(pu_grid(np * (C / VEC))), dim3(256), 0, st,
                                (const T*)dy, lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx);
