@@ -473,7 +473,9 @@ def main():
             traffic, traffic_note = None, f"no usable traffic profile ({e.__class__.__name__})"
         roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0]}
+                "avg_launch_ms": round(dom[1][1] / dom[1][0] * 1e3, 4), "launches_per_step": dom[0] and dom[1][0],
+                "timing": "HIP events around every launch in ONE extra step run on the launch stream alone (every kernel by itself, "
+                          "whatever config.streams says about the timed steps)"}
         if args.fp32 and args.bf16x3 and dom[0].startswith("conv3x3_"):
             # fp32 tensors, products on the bf16 matrix pipe as three bf16 products each (hi*hi + hi*lo + lo*hi): the pipe that
             # bounds the kernel is the bf16 one and it executes 3x the algorithmic FLOPs -- quoted against THAT peak (dividing
