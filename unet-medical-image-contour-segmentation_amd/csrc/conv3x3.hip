@@ -1170,9 +1170,49 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
             constexpr bool BQ2 = NBW == 1;              // two batches in flight (NBW = 2: one at a time -- no time difference in an A/B of the three schedules, fewest spills)
             if constexpr (BQ2) bq_load(bqA, 0);
             float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};
+#ifndef UH_BSUM_PK
+#define UH_BSUM_PK 1
+#endif
             auto bq_sum = [&](const u32x2 (&src)[8], int bi) {
                 const int n = bi >> 1, i0 = (bi & 1) * 8;
                 const int c0 = ch(kg_o, n, 0);
+#if UH_BSUM_PK
+                // two channels at a time as packed fp32 pairs (the two halves of a q dword, accumulators j, j + 1 = an aligned
+                // register pair): v_pk_fma / v_pk_add for the mask argument, q - mean and both sums -- 10 VALU instructions per
+                // pair and row instead of 14, every channel's operations and their order unchanged (bit-identical sums)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int jp = 0; jp < 4; jp += 2) {
+                    const f32x2 sc = *reinterpret_cast<const f32x2*>(&bs_tab[0 * BN + c0 + jp]);
+                    const f32x2 sh = *reinterpret_cast<const f32x2*>(&bs_tab[1 * BN + c0 + jp]);
+                    const f32x2 mu = *reinterpret_cast<const f32x2*>(&bs_tab[2 * BN + c0 + jp]);
+                    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                    if (bi & 1) { s1 = f32x2{p1[jp], p1[jp + 1]}; s2 = f32x2{p2[jp], p2[jp + 1]}; }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned pk = src[i][jp >> 1];
+                        const f32x2 qv = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+                        const f32x2 pre = __builtin_elementwise_fma(qv, sc, sh);       // the ReLU mask, as uh_bn_relu_apply decided it
+                        const f32x2 g = {pre[0] > 0.f ? acc[i0 + i][n][jp] : 0.f, pre[1] > 0.f ? acc[i0 + i][n][jp + 1] : 0.f};
+                        s1 += g;
+                        s2 = __builtin_elementwise_fma(g, qv - mu, s2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (bi & 1) {
+                            const float a1 = uh_row16_sum(s1[e]), a2 = uh_row16_sum(s2[e]);
+                            if (lx_o == 0) {
+                                S1[c0 + jp + e] += a1;
+                                S2[c0 + jp + e] += a2;
+                            }
+                        } else {
+                            p1[jp + e] = s1[e];
+                            p2[jp + e] = s2[e];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // one channel pair at a time
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float sc = bs_tab[0 * BN + c0 + j], sh = bs_tab[1 * BN + c0 + j], mu = bs_tab[2 * BN + c0 + j];
@@ -1198,6 +1238,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
                     }
                     __builtin_amdgcn_sched_barrier(0);       // one channel at a time (left free, the scheduler interleaves all four: +40 registers)
                 }
+#endif
             };
 #pragma unroll
             for (int bi = 0; bi < BQB; ++bi) {
