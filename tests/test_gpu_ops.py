@@ -265,6 +265,38 @@ def test_upsample_bilinear_pad(dtype, B, h, w, C, Ho, Wo):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,h,w,C,Ho,Wo", [(2, 32, 32, 64, 64, 64), (2, 12, 19, 64, 25, 39), (1, 8, 9, 8, 17, 19), (2, 2, 2, 8, 4, 4),
+                                           (1, 40, 33, 16, 81, 67), (4, 64, 48, 64, 128, 96), (1, 6, 7, 24, 12, 14)])
+def test_upsample_backward_buffer_and_pointer_forms_agree(dtype, B, h, w, C, Ho, Wo, monkeypatch):
+    """The strip form of the bilinear backward reads dy through a buffer descriptor (unused columns / rows get out-of-range offsets
+    and read zeros) for tensors below 1 GiB and through clamped pointers + selects above: the two must be bit-identical, padding
+    included, and a NaN / Inf in an output pixel must reach exactly the inputs that pixel is interpolated from in both."""
+    from unet_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 * h + w)
+    cot = torch.randn(B, Ho, Wo, C, generator=g)
+    if C >= 8:
+        cot[0, Ho // 2, Wo // 2, 3] = float("nan")
+        cot[B - 1, Ho // 3, Wo // 3, 5] = float("inf")
+    dy = cot.to(dtype).to(dev)
+    pt, pl = (Ho - 2 * h) // 2, (Wo - 2 * w) // 2
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("UH_UP_BWD_PTR", force)
+        dx = torch.full((B, h, w, C), 7.0, dtype=dtype, device=dev)
+        ops.LIB.call("uh_upsample2x_bwd", dy.data_ptr(), C, dx.data_ptr(), C, B, h, w, C, Ho, Wo, pt, pl, ops._dt(dy), ops._stream())
+        torch.cuda.synchronize()
+        out.append(dx.cpu())
+    a, b = out
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.equal(torch.nan_to_num(a.float(), nan=0.0, posinf=1e30, neginf=-1e30), torch.nan_to_num(b.float(), nan=0.0, posinf=1e30, neginf=-1e30))
+    if C >= 8:
+        # the NaN stays inside the 2 x 2 inputs of its output pixel (and its channel)
+        bad = torch.isnan(a[0].float())
+        assert bad.any() and bad.sum() <= 4 and bad[..., 3].sum() == bad.sum()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 64), (2, 15, 19, 8), (1, 6, 6, 3), (2, 8, 8, 512)])
 def test_maxpool_and_poolsplit(dtype, B, H, W, C):
     from unet_amd import ops

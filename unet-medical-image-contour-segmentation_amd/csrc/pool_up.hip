@@ -556,7 +556,10 @@ extern "C" int uh_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
             while (ty > 2 && (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC) < 256 * 1024) ty >>= 1;
             const int64_t nthr = (int64_t)B * ((h + ty - 1) / ty) * w * (C / VEC);
             const int64_t dyb = (int64_t)B * Ho * Wo * lddy * (int64_t)sizeof(T);
-            if (dyb < (1ll << 30))
+            // (UH_UP_BWD_PTR=1, read per call: the pointer form that tensors of 1 GiB and more take, for the test that holds the two
+            // forms bit-identical)
+            const char* force_ptr = getenv("UH_UP_BWD_PTR");
+            if (dyb < (1ll << 30) && !(force_ptr && force_ptr[0] == '1'))
                 hipLaunchKernelGGL((upsample2x_bwd_strip_kernel<T, VEC, true>), dim3(pu_grid(nthr)), dim3(256), 0, st, (const T*)dy,
                                    lddy, (T*)dx, lddx, B, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, ty, (unsigned)dyb);
             else
