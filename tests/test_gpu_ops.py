@@ -42,6 +42,9 @@ SHAPES_MULTITILE = [
     (2, 320, 336, 64, 0, 128),       # 840 tiles x 1 slab > 512 workgroups (NBW = 2)
     (1, 448, 448, 64, 64, 64),       # two-source K loop across tiles (the decoder's virtual concat)
     (3, 250, 333, 128, 0, 64),       # odd sizes: partial tiles on both edges, 1008 tiles
+    (4, 320, 320, 64, 0, 64),        # 1 600 tiles on 512 workgroups of the register-resident-filter form: 3-4 tiles each, so its
+                                     # three halo buffers (the DMA a whole tile ahead) go round more than once
+    (2, 333, 250, 64, 0, 64),        # the same with partial tiles on both edges (672 tiles: 1-2 each, border and interior mixed)
 ]
 
 
