@@ -182,8 +182,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 // the vertical blend reads the two rows where they are (one scalar branch per (a, bb) pair) and padding columns carry zeros through
 // it: 188.6 -> 164.3 us over the four Up-block shapes of config 2, bit-identical.  Eight
 // rows per thread (six input rows instead of two groups of four: a quarter fewer loads) measured no different (188.3 vs 188.6 us
-// over the four shapes): the longer pick chains cost what the loads save.
-constexpr int UP_ROWS = 4;
+// over the four shapes): the longer pick chains cost what the loads save -- and after the diet above they lose (161.5 -> 181 us,
+// -DUH_UP_ROWS=8: the 48 row registers cost occupancy).
+#ifndef UH_UP_ROWS
+#define UH_UP_ROWS 4
+#endif
+constexpr int UP_ROWS = UH_UP_ROWS;
 template <typename T, int V, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                                   int h, int w, int C, int Ho, int Wo, int pt, int pl,
