@@ -17,7 +17,10 @@ G4 Up convT, G5 OutConv, G6 Dice, G7 boundary_loss, G8 UNet_T 3-step trajectorie
 G9 full UNet scalars, G10 eval-mode logits/masks, G11 depth-5 net from reference parts,
 G12 utils/data_loading.BasicDataset items on synthetic PNG files,
 G13 full-width config-4 / config-5 nets on small images (scalars + first logits),
-G14 full UNet(1,1,bilinear=True) in eval mode at 2x1x512x512: logits, `logit > 0` masks, margin histogram, Dice.
+G14 full UNet(1,1,bilinear=True) in eval mode at 2x1x512x512: logits, `logit > 0` masks, margin histogram, Dice,
+G15 the reference under torch.autocast('cpu', bfloat16) (train.py:116,233: AMP is the CLI default) NEXT TO its own fp32
+result on the same inputs: DoubleConv(64,128) fwd/bwd, UNet_T 3-step trajectory, UNet(1,1,True) 2x1x64x64 step 0,
+G16 UNet_S(1,3,bilinear=False) -- the reference CLI's default model and class count (train.py:253,235) -- 3-step trajectory.
 """
 import os
 import sys
@@ -408,6 +411,141 @@ def g14_eval_full_unet():
     save("g14_eval_full_unet_512", **rec)
 
 
+def amp_ctx(amp):
+    return torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp)          # train.py:116 on a CUDA-less host
+
+
+def g15_bf16_doubleconv():
+    """One DoubleConv(64,128) forward + backward, fp32 and under CPU bf16 autocast, same weights / input / cotangent."""
+    g = torch.Generator().manual_seed(150)
+    torch.manual_seed(15)
+    m = DoubleConv(64, 128); randomize_bn(m, 15)
+    m.train()
+    x = torch.randn(2, 64, 24, 40, generator=g)
+    cot = torch.randn(2, 128, 24, 40, generator=g)
+    rec = sd_np(m, "sd0.")
+    rec["x0"], rec["cot"] = npy(x), npy(cot)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    for tag, amp in (("ref32", False), ("ref16", True)):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        with amp_ctx(amp):
+            y = m(xr)
+        rec[tag + ".y_dtype"] = np.array(str(y.dtype))
+        y.float().backward(cot)
+        rec[tag + ".y"] = npy(y.float())
+        rec[tag + ".dx0"] = npy(xr.grad)
+        for k, p in m.named_parameters():
+            rec[tag + ".grad." + k] = npy(p.grad)
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                rec[tag + ".sd1." + k] = npy(v)
+    save("g15_bf16_doubleconv_64_128", **rec)
+
+
+def ref_train_steps_amp(model, batches, n_classes, amp, lr=1e-5):
+    """ref_train_steps with train.py:116's autocast around forward + loss (GradScaler is disabled on a CUDA-less host:
+    scale(loss) is loss, unscale_ / update are no-ops -- train.py:84,154-159)."""
+    opt = torch.optim.RMSprop(model.parameters(), lr=lr, weight_decay=1e-8, momentum=0.999, foreach=True)
+    crit = nn.CrossEntropyLoss() if n_classes > 1 else nn.BCEWithLogitsLoss()
+    model.train()
+    rec = {}
+    for s, (images, masks) in enumerate(batches):
+        true_masks = masks.clone()
+        with amp_ctx(amp):
+            masks_pred = model(images)
+            if n_classes == 1:
+                true_masks //= 2
+                first = crit(masks_pred.squeeze(1), true_masks.float())
+                dl = dice_loss(torch.sigmoid(masks_pred.squeeze(1)), true_masks.float(), multiclass=False)
+                bl = boundary_loss(masks_pred.squeeze(1), true_masks.float(), edge_width=51, edge_weight=15)
+                loss = first + dl + 0.25 * bl
+            else:
+                first = crit(masks_pred, true_masks)
+                dl = dice_loss(F.softmax(masks_pred, dim=1).float(),
+                               F.one_hot(true_masks, n_classes).permute(0, 3, 1, 2).float(), multiclass=True)
+                bl = torch.zeros(())
+                loss = first + dl
+        assert not torch.isnan(loss).any()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        rec[f"s{s}.{'bce' if n_classes == 1 else 'ce'}"] = npy(first.float())
+        rec[f"s{s}.dice"] = npy(dl.float())
+        rec[f"s{s}.boundary"] = npy(bl.float())
+        rec[f"s{s}.loss"] = npy(loss.float())
+        rec[f"s{s}.grad_norm"] = npy(gn)
+        rec[f"s{s}.logits"] = npy(masks_pred.float())
+        if s == 0:
+            for k, p in model.named_parameters():
+                rec["s0.grad." + k] = npy(p.grad)          # after clipping
+        opt.step()
+    rec.update(sd_np(model, f"sd{len(batches)}."))
+    return rec
+
+
+def g15_bf16_unet_t():
+    """G8's UNet_T(1,1,bilinear) trajectory (same weights, same batches) under bf16 autocast, with the fp32 one beside it."""
+    batches = [synth_batch(100 + s, 2, 1, 64, 64) for s in range(3)]
+    rec = {}
+    for tag, amp in (("ref32", False), ("ref16", True)):
+        torch.manual_seed(0)
+        m = UNet_T(1, 1, bilinear=True)
+        if not rec:
+            rec.update(sd_np(m, "sd0."))
+        r = ref_train_steps_amp(m, batches, 1, amp)
+        rec.update({tag + "." + k: v for k, v in r.items()})
+    for s, (im, mk) in enumerate(batches):
+        rec[f"s{s}.images"], rec[f"s{s}.masks"] = npy(im), npy(mk)
+    save("g15_bf16_unet_t_bilinear", **rec)
+
+
+def g15_bf16_unet_full():
+    """UNet(1,1,bilinear=True) (weights torch.manual_seed(0) + ctor, not stored) on 2x1x64x64, step 0, fp32 and bf16
+    autocast: logits, loss terms, gradient norm; per parameter tensor the L2 norms of the fp32 gradient and of
+    (bf16 gradient - fp32 gradient) -- the reference's OWN bf16 error, the yardstick of the HIP bf16 path -- and the
+    gradients themselves for the tensors of at most 2^15 elements."""
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(2, 1, 64, 64, generator=g)
+    masks = torch.randint(0, 3, (2, 64, 64), generator=g)
+    rec = {"images": npy(images), "masks": npy(masks)}
+    grads = {}
+    for tag, amp in (("ref32", False), ("ref16", True)):
+        torch.manual_seed(0)
+        m = UNet(1, 1, bilinear=True)
+        r = ref_train_steps_amp(m, [(images, masks)], 1, amp)
+        grads[tag] = {k[8:]: v for k, v in r.items() if k.startswith("s0.grad.")}
+        rec.update({tag + "." + k: v for k, v in r.items() if k.startswith("s0.") and not k.startswith("s0.grad.")})
+    names = list(grads["ref32"])
+    rec["grad_names"] = np.array(names)
+    rec["grad_l2.ref32"] = np.array([np.linalg.norm(grads["ref32"][k].astype(np.float64)) for k in names])
+    rec["grad_l2.ref16"] = np.array([np.linalg.norm(grads["ref16"][k].astype(np.float64)) for k in names])
+    rec["grad_l2.diff"] = np.array([np.linalg.norm(grads["ref16"][k].astype(np.float64) - grads["ref32"][k]) for k in names])
+    for k in names:
+        if grads["ref32"][k].size <= 1 << 15:
+            rec["ref32.grad." + k], rec["ref16.grad." + k] = grads["ref32"][k], grads["ref16"][k]
+    rec["note"] = np.array("UNet(1,1,True): torch.manual_seed(0) + ctor; data Generator(1): rand(2,1,64,64), randint(0,3); "
+                           "gradients are AFTER clip_grad_norm_(1.0), as train.py:157 leaves them")
+    save("g15_bf16_unet_full_64", **rec)
+
+
+def g16_unet_s():
+    """train.py:253,235: the CLI's default model UNet_S(n_channels=1, n_classes=3, bilinear=False); CE + multiclass Dice
+    (train.py:136-142), 3 steps, fp32.  Weights = torch.manual_seed(0) + ctor (not stored; per-tensor sums are)."""
+    torch.manual_seed(0)
+    m = UNet_S(1, 3, bilinear=False)
+    init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    batches = [synth_batch(700 + s, 2, 1, 64, 64, nmask=3) for s in range(3)]
+    rec = ref_train_steps_amp(m, batches, 3, False)
+    rec["sd0_names"] = np.array(list(init))
+    rec["sd0_sums"] = np.array([float(v.double().sum()) for v in init.values()])
+    rec["sd0_abs_sums"] = np.array([float(v.double().abs().sum()) for v in init.values()])
+    for s, (im, mk) in enumerate(batches):
+        rec[f"s{s}.images"], rec[f"s{s}.masks"] = npy(im), npy(mk)
+    save("g16_unet_s_convt_3class", **rec)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python make_golden.py g14_eval_full_unet  -> that generator only
         for name in sys.argv[1:]:
@@ -423,3 +561,7 @@ if __name__ == "__main__":
     g12_data_loading()
     g13_full_width()
     g14_eval_full_unet()
+    g15_bf16_doubleconv()
+    g15_bf16_unet_t()
+    g15_bf16_unet_full()
+    g16_unet_s()

@@ -152,12 +152,22 @@ def test_boundary_golden(case):
     check(got, r[case + ".loss"], 2e-5, case)
 
 
-def _run_traj(name, cls, args, n_classes, lr=1e-5, bmc=None, widths=None):
+def _run_traj(name, cls, args, n_classes, lr=1e-5, bmc=None, widths=None, seeded_init=None):
     import unet_amd
     dev = _dev()
     r = load_golden(name)
-    model = (unet_amd.UNetDepth(*args, widths=widths) if widths else cls(*args)).to(dev)
-    load_sd(model, r, "sd0.")
+    if seeded_init is not None:
+        # the fixture stores no initial state: weights = torch.manual_seed(seed) + ctor on the CPU (the drop-in classes create
+        # their parameters in the reference's order with the reference's initialisers), checked against the stored sums
+        torch.manual_seed(seeded_init)
+        model = cls(*args)
+        for k, v, want, scale in zip(model.state_dict(), model.state_dict().values(), r["sd0_sums"], r["sd0_abs_sums"]):
+            assert k == str(r["sd0_names"][list(model.state_dict()).index(k)])
+            assert abs(float(v.double().sum()) - want) <= 1e-9 * max(scale, 1.0), k
+        model = model.to(dev)
+    else:
+        model = (unet_amd.UNetDepth(*args, widths=widths) if widths else cls(*args)).to(dev)
+        load_sd(model, r, "sd0.")
     stepper = unet_amd.TrainStepper(model, lr=lr, amp=False)
     nsteps = sum(1 for k in r if k.endswith(".images"))
     for s in range(nsteps):
@@ -206,6 +216,13 @@ def test_unet_t_convt_trajectory():
 def test_unet_t_multiclass_trajectory():
     import unet_amd
     _run_traj("g8_unet_t_multiclass", unet_amd.UNet_T, (3, 4, True), 4)
+
+
+def test_unet_s_default_model_trajectory():
+    """Fixture G16: UNet_S(1, 3, bilinear=False), the model and class count the reference's CLI builds by default
+    (train.py:253,235): CE + multiclass Dice, transposed-conv Up blocks, 16 ... 256 channels (the narrow-tensor kernels)."""
+    import unet_amd
+    _run_traj("g16_unet_s_convt_3class", unet_amd.UNet_S, (1, 3, False), 3, seeded_init=0)
 
 
 def test_depth5_multiclass_trajectory():

@@ -9,22 +9,37 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# The PRE instantiations have no K-split form (KS = 2 adds the two halves of the contraction in another order): when this module
-# runs against the flagged library, the stored-activation leg takes the unsplit kernel too, so that "bit-identical" compares
-# the same summation order.  (Read once by the library, at its first conv dispatch: set at collection time, before any launch.)
-if "libunet_hip_pre" in os.environ.get("UH_LIB_PATH", ""):
-    os.environ.setdefault("UH_NO_KSPLIT", "1")
+PRE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unet-medical-image-contour-segmentation_amd",
+                       "libunet_hip_pre.so")
 
 
-@pytest.fixture(autouse=True)
-def _needs_the_pre_build():
+@pytest.fixture(autouse=True, scope="module")
+def _bind_the_pre_build():
     """The PRE instantiations are a measured net loss and live behind a build flag: the default library
-    answers uh_conv3x3_pre_ok with 0 and refuses the two entry points.  Build and select the flagged library with
-        UH_BUILD_PRE=1 python unet-medical-image-contour-segmentation_amd/build.py
-        UH_LIB_PATH=$PWD/unet-medical-image-contour-segmentation_amd/libunet_hip_pre.so python -m pytest tests/test_gpu_pre_fusion.py -m gpu"""
-    from unet_amd._lib import LIB, UH_BF16
-    if not LIB.query("uh_conv3x3_pre_ok", 2, 64, 64, 128, 256, 128, 256, UH_BF16):
-        pytest.skip("this library was built without UH_BUILD_PRE=1")
+    answers uh_conv3x3_pre_ok with 0 and refuses the two entry points.  __graft_entry__.build() builds the flagged library beside
+    the default one (same C ABI, own object directory); for the length of this module the ctypes binding points at it, so that
+    the driver's one `pytest -m gpu` session covers the kernel family too.
+    The PRE instantiations have no K-split form (KS = 2 adds the two halves of the contraction in another order): the
+    stored-activation leg of the flagged library takes the unsplit kernel too (UH_NO_KSPLIT, read once per LIBRARY at its first
+    conv dispatch), so that "bit-identical" compares the same summation order."""
+    from unet_amd import _lib
+    if not os.path.exists(PRE_LIB):
+        pytest.fail(f"{PRE_LIB} is missing: __graft_entry__.build() builds it")
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    saved = (_lib.LIB._dll, _lib.LIB_PATH, os.environ.get("UH_NO_KSPLIT"))
+    os.environ["UH_NO_KSPLIT"] = "1"
+    _lib.LIB_PATH, _lib.LIB._dll = PRE_LIB, None
+    _lib.LIB.load()
+    assert _lib.LIB.query("uh_conv3x3_pre_ok", 2, 64, 64, 128, 256, 128, 256, _lib.UH_BF16), "libunet_hip_pre.so lacks the PRE kernels"
+    yield
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _lib.LIB._dll, _lib.LIB_PATH = saved[0], saved[1]
+    if saved[2] is None:
+        os.environ.pop("UH_NO_KSPLIT", None)
+    else:
+        os.environ["UH_NO_KSPLIT"] = saved[2]
 
 
 def _dev():

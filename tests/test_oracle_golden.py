@@ -122,7 +122,10 @@ def test_boundary(case):
 
 
 def run_traj(name, n_classes, bilinear, depth=4, lr=1e-5, bmc=0.0):
-    r = load_golden(name)
+    _run_traj_rec(load_golden(name), n_classes, bilinear, depth, lr, bmc)
+
+
+def _run_traj_rec(r, n_classes, bilinear, depth=4, lr=1e-5, bmc=0.0, widths=None):
     st = state_from(r, "sd0.")
     opt = None
     nsteps = sum(1 for k in r if k.endswith(".images"))
@@ -209,3 +212,84 @@ def test_init_state_keys_match_reference():
     assert sorted(st.keys()) == ref_keys
     for k in ref_keys:
         assert tuple(st[k].shape) == tuple(r["sd0." + k].shape), k
+
+
+# ------------------------------------------------------------------ G16: the reference CLI's default model (train.py:253,235)
+def _unet_s_init():
+    """UNet_S(1, 3, bilinear=False) weights = torch.manual_seed(0) + the drop-in ctor (same module order and initialisers as the
+    reference's); the fixture's per-tensor sums check that before anything is compared."""
+    import unet_amd
+    r = load_golden("g16_unet_s_convt_3class")
+    torch.manual_seed(0)
+    model = unet_amd.UNet_S(1, 3, bilinear=False)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert list(sd) == [str(k) for k in r["sd0_names"]]
+    for k, s, a in zip(sd, r["sd0_sums"], r["sd0_abs_sums"]):
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(a, 1.0), k
+    return r, sd
+
+
+def test_unet_s_default_model_traj():
+    r, st = _unet_s_init()
+    r = dict(r)
+    r.update({"sd0." + k: v.numpy() for k, v in st.items()})
+    _run_traj_rec(r, 3, False, widths=(16, 32, 64, 128, 256))
+
+
+# ------------------------------------------------------------------ the torch.nn restatement (bench.py's cpu_baseline graph)
+def _nn_model(rec_sd, n_channels, n_classes, bilinear, widths):
+    from oracle import nn_ref as N
+    m = N.NNUNet(n_channels, n_classes, bilinear, widths)
+    assert list(m.state_dict()) == list(rec_sd), "state_dict keys / order differ from the reference's"
+    m.load_state_dict(rec_sd)
+    return m
+
+
+def _l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("name,n_in,ncls,bilinear", [("g8_unet_t_bilinear", 1, 1, True), ("g8_unet_t_convt", 1, 1, False),
+                                                     ("g8_unet_t_multiclass", 3, 4, True)])
+def test_nn_restatement_reproduces_the_reference_trajectories(name, n_in, ncls, bilinear):
+    from oracle import nn_ref as N
+    r = load_golden(name)
+    m = _nn_model(state_from(r, "sd0."), n_in, ncls, bilinear, (8, 16, 32, 64, 128))
+    stepper = N.NNStepper(m, lr=1e-5)
+    nsteps = sum(1 for k in r if k.endswith(".images"))
+    for s in range(nsteps):
+        info = stepper.step(T(r[f"s{s}.images"]), T(r[f"s{s}.masks"]))
+        close(info["logits"], r[f"s{s}.logits"], rtol=2e-4, atol=2e-5) if s == 0 else None
+        close(info["loss"], r[f"s{s}.loss"], rtol=1e-5 if s == 0 else 2e-3)
+        close(info["grad_norm"], r[f"s{s}.grad_norm"], rtol=1e-4 if s == 0 else 2e-2)
+        if s == 0:
+            for k, g in info["grads"].items():
+                close(g, r[f"s0.grad.{k}"], rtol=1e-3, atol=1e-4)
+    for k, v in state_from(r, f"sd{nsteps}.").items():
+        if not k.endswith("num_batches_tracked"):
+            close(m.state_dict()[k], v, rtol=1e-3, atol=5e-4)
+
+
+def test_nn_restatement_under_bf16_autocast_is_the_reference_under_bf16_autocast():
+    """G15: the same stock modules under torch.autocast('cpu', bfloat16) take the reference's dtypes op by op; what is left is
+    oneDNN's blocking at another thread count.  Held against the reference's bf16 result at a fraction of the reference's own
+    bf16-vs-fp32 distance."""
+    from oracle import nn_ref as N
+    r = load_golden("g15_bf16_unet_t_bilinear")
+    m = _nn_model(state_from(r, "sd0."), 1, 1, True, (8, 16, 32, 64, 128))
+    stepper = N.NNStepper(m, lr=1e-5, amp=True)
+    info = stepper.step(T(r["s0.images"]), T(r["s0.masks"]))
+    own = _l2(r["ref16.s0.logits"], r["ref32.s0.logits"])
+    assert _l2(info["logits"], r["ref16.s0.logits"]) <= 0.25 * own
+    for q in ("bce", "dice", "loss"):
+        assert abs(float(info[q]) - float(r[f"ref16.s0.{q}"])) <= 4e-3 * abs(float(r[f"ref16.s0.{q}"])), q     # one bf16 ulp
+    assert abs(float(info["grad_norm"]) - float(r["ref16.s0.grad_norm"])) <= 2e-2 * float(r["ref16.s0.grad_norm"])
+
+
+def test_bf16_fixtures_carry_the_fp32_trajectory_of_g8():
+    """G15's fp32 leg is G8's run again (same weights, same batches): the two generators agree."""
+    a, b = load_golden("g15_bf16_unet_t_bilinear"), load_golden("g8_unet_t_bilinear")
+    for s in range(3):
+        close(a[f"ref32.s{s}.loss"], b[f"s{s}.loss"], rtol=1e-6)
+        close(a[f"ref32.s{s}.logits"], b[f"s{s}.logits"], rtol=1e-5, atol=1e-6)

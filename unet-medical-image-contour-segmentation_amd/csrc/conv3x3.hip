@@ -2701,7 +2701,7 @@ template <typename T, int NWR, bool PRE = false, bool SLAB16 = false>
 __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
-    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv, const float* __restrict__ pre_scale = nullptr,
+    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv, int strided, const float* __restrict__ pre_scale = nullptr,
     const float* __restrict__ pre_shift = nullptr) {
     static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
     constexpr int TH = 8;
@@ -2737,8 +2737,13 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 
     const int ntile = B * tilesX * tilesY;
     const int split = blockIdx.x;
-    const int t_begin = (int)(((int64_t)ntile * split) / nsplit);
-    const int t_end = (int)(((int64_t)ntile * (split + 1)) / nsplit);
+    // strided != 0 (default): split s owns tiles s, s + nsplit, s + 2 nsplit, ... -- every partial sum then samples the whole batch
+    // extent instead of one contiguous range of tile rows, so that a gradient whose SIGN follows image regions (foreground against
+    // background: after BatchNorm backward it sums to zero over the batch) cancels inside the fp32 accumulators, not between
+    // partials that were rounded to bf16 on the way to the reduce kernel (SLAB16); strided == 0: contiguous ranges (UH_WGRAD_CONTIG=1)
+    const int tstep = strided ? nsplit : 1;
+    const int t_begin = strided ? split : (int)(((int64_t)ntile * split) / nsplit);
+    const int t_end = strided ? ntile : (int)(((int64_t)ntile * (split + 1)) / nsplit);
 
     // per-thread DMA geometry that does not depend on the tile: halo coordinates of each 16-byte unit and its byte
     // offset relative to the tile's top-left halo pixel (tile-dependent part is one scalar base + 4 range checks)
@@ -2978,14 +2983,14 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     ld_d(lds + XBYTES, 0);
     ld_x(lds, 0);
     int bufi = 0;
-    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+    for (int tile = t_begin; tile < t_end; tile += tstep, bufi ^= 1) {
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
         // the next tile's DMA, into the buffer the last fence released (behind this tile's first fragment reads, which were
         // issued in front of pair 5 of the previous tile; issuing it there as well -- with pair 5's fragments still live --
         // spilled ~30 registers into the MFMA stream)
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 5; ++a) {
@@ -2995,7 +3000,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
             mma_pair(a);
         }
         // every LDS read of this tile has been issued (pair 5's in front of pair 4's MFMAs)
-        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
+        tile_fence(tile + tstep, bufi ^ 1, tile + tstep < t_end);
         {
             // (unconditional: behind the last tile these sixteen reads fetch stale LDS contents nobody uses -- a branch here
             // makes the fragments phi nodes of the loop and costs ~20 spilled registers around the fence)
@@ -3012,9 +3017,9 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     if (t_begin < t_end) issue(t_begin, 0);
     tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
-    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
+    for (int tile = t_begin; tile < t_end; tile += tstep, bufi ^= 1) {
 #if !UH_WGRAD_M16
-        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #endif
         const unsigned char* xs = lds + bufi * STAGE;
@@ -3042,7 +3047,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         // released from the barrier and the matrix pipe empty; now it runs under the LDS latency of the reads the first MFMAs wait
         // for (profiles/r03_wgrad_phase_stamps.txt).  The buffer it writes was released by the barrier at the end of the last tile.
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
+        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -3089,7 +3094,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
                         acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
 #endif
-        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
+        tile_fence(tile + tstep, bufi ^ 1, tile + tstep < t_end);
     }
     }
 
@@ -3523,6 +3528,7 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     float* slabs = (float*)ws;
     // bf16-pair slabs: the bf16 LDS-DMA kernel's default (see SLAB16)
     static const bool slab_f32 = getenv("UH_WGRAD_SLAB_F32") != nullptr && getenv("UH_WGRAD_SLAB_F32")[0] == '1';
+    static const int strided = (getenv("UH_WGRAD_CONTIG") != nullptr && getenv("UH_WGRAD_CONTIG")[0] == '1') ? 0 : 1;
     const bool slab16 = ES == 2 && p.kind == 0 && dma && !slab_f32 && UH_WGRAD_M16 && uh_aligned16(dw);
     if (p.kind == 0) {
         const int64_t npx = (int64_t)B * H * W;
@@ -3534,7 +3540,7 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
 #define UH_LAUNCH_WGRAD_V2(NWR_, PRE_, S16_)                                                                                      \
     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, NWR_, PRE_, S16_>), dim3(p.nsplit, (Cin / 64) * (Cout / (32 * NWR_))),           \
                        dim3(128 * NWR_), 0, st, dy, lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY,      \
-                       p.nsplit, db, xb, C0v, C1v, Coutv, pre_scale, pre_shift)
+                       p.nsplit, db, xb, C0v, C1v, Coutv, strided, pre_scale, pre_shift)
 #if UH_BUILD_PRE
                 if (pre) {
                     if (p.nwr == 4) { if (slab16) UH_LAUNCH_WGRAD_V2(4, true, true); else UH_LAUNCH_WGRAD_V2(4, true, false); }
