@@ -78,38 +78,50 @@ def parse():
 
 
 def cpu_baseline(size: int):
-    """The CPU oracle (oracle/step_ref.py: stock PyTorch restatement of train.py:113-159, pinned to the reference's golden
-    fixtures) timed on this host: BASELINE config 1 = batch 2, 1x512x512; fp32 (amp=False, the parity leg) and CPU bf16
-    autocast (= the reference CLI's default --amp on a CUDA-less host, train.py:116,233).  1 warm-up + best of 3 each
-    (SURVEY.md 8d)."""
+    """The reference's train step from stock torch.nn modules (oracle/nn_ref.py: nn.Conv2d / BatchNorm2d / Upsample ... wired as
+    unet_parts.py / unet_model.py wire them, stock RMSprop + clip_grad_norm_, pinned to the reference's golden fixtures in fp32
+    AND under bf16 autocast: G8 / G15) timed on this host: BASELINE config 1 = batch 2, 1x512x512; fp32 (amp=False, the parity
+    leg) and CPU bf16 autocast (= the reference CLI's default --amp on a CUDA-less host, train.py:116,233).  1 warm-up + best of
+    3 each.  `functional_restatement` times oracle/step_ref.py (written-out BatchNorm backward, clip and RMSprop:
+    the checker of the parity tests) on the same step for comparison."""
+    from oracle import nn_ref as N
     from oracle import step_ref as S
     from oracle import unet_ref as U
     # the GPU box gives one GPU a share of 16 host cores (the machine shows 256): oversubscribing slows oneDNN down
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
-    images = torch.rand(2, 1, size, size, generator=g)
+    images = torch.rand(2, 1, size, size, generator=g).contiguous(memory_format=torch.channels_last)      # train.py:113
     masks = torch.randint(0, 3, (2, size, size), generator=g)
     nsteps = 3
     legs = {}
     for name, amp in (("fp32", False), ("bf16_autocast", True)):
-        st = U.init_state(1, 1, True, seed=0)
-        opt = None
-        st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True, amp=amp)      # warm-up
+        torch.manual_seed(0)
+        model = N.NNUNet(1, 1, True).to(memory_format=torch.channels_last)                               # train.py:262
+        stepper = N.NNStepper(model, amp=amp)
+        stepper.step(images, masks)                                                                       # warm-up
         best = float("inf")
         for _ in range(nsteps):
             t0 = time.perf_counter()
-            st, opt, _ = S.train_step(st, opt, images, masks, n_classes=1, bilinear=True, amp=amp)
+            stepper.step(images, masks)
             best = min(best, time.perf_counter() - t0)
         legs[name] = {"images_per_sec": round(2.0 / best, 4), "s_per_step": round(best, 3)}
+    st = U.init_state(1, 1, True, seed=0)
+    st, opt, _ = S.train_step(st, None, images, masks, n_classes=1, bilinear=True)
+    t0 = time.perf_counter()
+    S.train_step(st, opt, images, masks, n_classes=1, bilinear=True)
+    func = time.perf_counter() - t0
     return {"value": legs["fp32"]["images_per_sec"], "unit": "images/sec", "cores": torch.get_num_threads(),
             "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"oracle/step_ref.train_step, UNet(1,1,bilinear=True) fp32 (amp=False), batch 2 x 1x{size}x{size}, "
+            "graph": "torch.nn modules (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.MaxPool2d, nn.Upsample), channels_last, torch.optim.RMSprop(foreach) "
+                     "+ clip_grad_norm_: oracle/nn_ref.py, the reference's own graph restated (the reference's Python does not travel)",
+            "sample": f"UNet(1,1,bilinear=True) fp32 (amp=False), batch 2 x 1x{size}x{size}, "
                       f"1 warm-up + best of {nsteps} steps ({legs['fp32']['s_per_step']:.2f} s/step)",
             "bf16_autocast": {"value": legs["bf16_autocast"]["images_per_sec"], "unit": "images/sec",
                               "sample": f"same step under torch.autocast('cpu', bfloat16) (the reference CLI default), "
                                         f"1 warm-up + best of {nsteps} ({legs['bf16_autocast']['s_per_step']:.2f} s/step); "
-                                        "timing only, the fixtures pin the fp32 leg"}}
+                                        "pinned by fixture set G15"},
+            "functional_restatement": {"value": round(2.0 / func, 4), "unit": "images/sec",
+                                       "sample": f"oracle/step_ref.train_step (fp32), one step behind a warm-up ({func:.2f} s/step)"}}
 
 
 def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e-4, seeds=(0, 1, 2, 3, 4), extra=(225, 250)):
@@ -150,6 +162,30 @@ def dice_vs_ref(steps: int = 200, size: int = 64, batch: int = 4, lr: float = 1e
         avg.append(round(sum(ds) / len(ds), 4))
     out.update({"ref_cpu_fp32": med(at), "ref_cpu_fp32_runs": at, "ref_cpu_fp32_avg": med(avg), "ref_cpu_fp32_avg_runs": avg,
                 "ref_cpu_seconds": round(time.perf_counter() - t0, 1)})
+    # the reference's OWN bf16 (train.py:116 autocast, its CLI default): the same recipe on the torch.nn graph (oracle/nn_ref.py)
+    # under torch.autocast('cpu', bfloat16) -- the like-for-like column for hip_bf16
+    from oracle import nn_ref as N
+    t0 = time.perf_counter()
+    at, avg = [], []
+    for seed in seeds:
+        twin = N.NNUNet(1, 1, True, widths)
+        twin.load_state_dict({k: v.clone() for k, v in inits[seed].items()})
+        stepper, ds = N.NNStepper(twin, lr=lr, amp=True), []
+        for i in range(max(marks)):
+            im, mk = train[i % len(train)]
+            stepper.step(im, mk)
+            if i + 1 in marks:
+                twin.eval()
+                with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):                 # evaluate.py:43
+                    logits = twin(held[0]).float()
+                twin.train()
+                pred = (torch.sigmoid(logits.squeeze(1)) > 0.5).float()
+                from oracle import losses_ref as L
+                ds.append(float(L.dice_coeff(pred, (held[1] // 2).float(), reduce_batch_first=False)))
+        at.append(round(ds[0], 4))
+        avg.append(round(sum(ds) / len(ds), 4))
+    out.update({"ref_cpu_bf16": med(at), "ref_cpu_bf16_runs": at, "ref_cpu_bf16_avg": med(avg), "ref_cpu_bf16_avg_runs": avg,
+                "ref_cpu_bf16_seconds": round(time.perf_counter() - t0, 1)})
     dev = torch.device("cuda", torch.cuda.current_device())
     held_set = [{"image": held[0], "mask": held[1]}]
     for name, amp in (("hip_fp32", False), ("hip_bf16", True)):

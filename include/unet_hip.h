@@ -129,14 +129,17 @@ int uh_stem_bn_relu_bwd_wgrad(const void* dz, int lddz, const void* x, int Cin, 
 int uh_conv3x3_fwd_affine_relu(const void* x0, int C0, int ld0, const void* x1, int C1, int ld1,
                                const void* w, void* z, int ldz, int Cout, const float* scale,
                                const float* shift, int B, int H, int W, int dt, uh_stream stream);
-/* conv backward-weights: dw[o][r][s][i] = sum_{b,h,w} dy[b,h,w,o] * x[b,h+r-1,w+s-1,i] (fp32 KRSC). */
+/* conv backward-weights: dw[o][r][s][i] = sum_{b,h,w} dy[b,h,w,o] * x[b,h+r-1,w+s-1,i] (fp32 KRSC).
+ * bf16 MFMA path: the per-split partial sums (fp32 accumulators) travel through `ws` as block-scaled fp16 -- 11 significant
+ * bits, one power-of-two scale per workgroup block -- and are added in fp32 in a fixed order (deterministic); UH_WGRAD_SLAB_F32=1
+ * in the environment keeps them fp32. */
 size_t uh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dt);
 int uh_conv3x3_wgrad(const void* dy, int lddy, const void* x0, int C0, int ld0,
                      const void* x1, int C1, int ld1, float* dw_krsc, int Cout,
                      void* ws, size_t ws_bytes, int B, int H, int W, int dt, uh_stream stream);
 /* Backward-weights in two stages, the second deferred and batched.  uh_conv3x3_wgrad_partials = uh_conv3x3_wgrad without its
  * closing reduction over the pixel splits: the partial results stay in `ws` (which must stay alive and untouched until the
- * reduction has run) and desc[0..7] -- HOST memory -- receives { slabs, dw_krsc, n, nsplit, format, row, blocks, 0 }; desc[3] == 0
+ * reduction has run) and desc[0..7] -- HOST memory -- receives { slabs, dw_krsc, n, nsplit, format, row, blocks, rows per scale block }; desc[3] == 0
  * means the shape took a path without slabs and dw_krsc is already final.  uh_slab_reduce_batched finishes any number of such
  * layers in ONE launch: `table` is DEVICE memory holding the rows (8 int64 each) with [6] replaced by the row's first block
  * (running sum of the block counts), total_blocks their sum.  Filter gradients only feed the optimizer (train.py:157-158), so

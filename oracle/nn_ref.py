@@ -35,6 +35,50 @@ def _conv_bn_relu_twice(cin: int, cout: int, mid: int) -> nn.Module:
     return holder
 
 
+def double_conv_module(cin: int, cout: int, mid: int = None) -> nn.Module:
+    """DoubleConv(in, out, mid) (unet_parts.py:7-24) with the reference's keys (``double_conv.N.*``)."""
+    blk = _conv_bn_relu_twice(cin, cout, mid or cout)
+    blk.forward = lambda x: blk.double_conv(x)
+    return blk
+
+
+def down_module(cin: int, cout: int) -> nn.Module:
+    """Down(in, out) (unet_parts.py:26-37), keys ``maxpool_conv.1.double_conv.N.*``."""
+    blk = nn.Module()
+    blk.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), _conv_bn_relu_twice(cin, cout, cout))
+    blk.forward = lambda x: blk.maxpool_conv[1].double_conv(blk.maxpool_conv[0](x))
+    return blk
+
+
+def up_module(cin: int, cout: int, bilinear: bool) -> nn.Module:
+    """Up(in, out, bilinear) (unet_parts.py:62-98), keys ``up.*`` (transposed conv only) and ``conv.double_conv.N.*``."""
+    blk = nn.Module()
+    blk.up = (nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) if bilinear
+              else nn.ConvTranspose2d(cin, cin // 2, kernel_size=2, stride=2))
+    blk.conv = _conv_bn_relu_twice(cin, cout, cin // 2 if bilinear else cout)
+
+    def forward(x1, x2):
+        y = blk.up(x1)
+        dy, dx = x2.shape[2] - y.shape[2], x2.shape[3] - y.shape[3]
+        y = F.pad(y, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return blk.conv.double_conv(torch.cat([x2, y], dim=1))
+    blk.forward = forward
+    return blk
+
+
+def block_fwd_bwd(blk: nn.Module, state: Dict[str, torch.Tensor], xs, cot: torch.Tensor, amp: bool):
+    """Train-mode forward + backward of one block on CPU, fp32 or under torch.autocast('cpu', bfloat16) (train.py:116):
+    -> (y as fp32, [dx...], {name: parameter gradient})."""
+    blk.load_state_dict(state)
+    blk.train()
+    blk.zero_grad(set_to_none=True)
+    xs = [x.detach().clone().requires_grad_(True) for x in xs]
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp):
+        y = blk.forward(*xs)
+    y.float().backward(cot)
+    return y.detach().float(), [x.grad for x in xs], {k: p.grad.detach().clone() for k, p in blk.named_parameters()}
+
+
 class NNUNet(nn.Module):
     """Any depth / width plan of ``unet_spec`` (the reference's UNet, UNet_S, UNet_T and BASELINE config 4's depth-5 net)."""
 

@@ -92,13 +92,16 @@ def test_b8_512_bf16_step_matches_fp32_path_at_the_same_size():
 
 
 def test_b8_512_logits_and_loss_against_the_cpu_oracle_directly():
-    """BASELINE config 2's exact batch (8 x 1x512x512) against the CPU oracle itself, not via the HIP fp32 path: one
+    """BASELINE config 2's exact batch (8 x 1x512x512) against the CPU restatements themselves, not via the HIP fp32 path: one
     oracle step (oracle/step_ref.train_step, pinned to the reference by G8 / G9) gives logits, loss terms and the gradient
-    norm; the HIP fp32 step must meet the north star's 1e-3 (loss terms 1e-4), the bf16 step the stated bf16 tolerances
-    (logits 8e-2 relative L2 -- measured 6.5e-2 --, loss 2e-2, gradient norm 1e-1: bf16 activations carry 8 significant bits
-    through 18 layers and the logits of a fresh net are small differences of large sums)."""
+    norm; the HIP fp32 step must meet the north star's 1e-3 (loss terms 1e-4).  The bf16 step -- the benchmarked arithmetic -- is
+    judged like for like: the reference's graph from stock torch.nn modules (oracle/nn_ref.py, bit-identical to fixture set G15)
+    runs the SAME step under torch.autocast('cpu', bfloat16) (train.py:116), and the HIP bf16 step may be no further from the
+    fp32 answer than 1.5 x that run is (tests/yardstick.py; round 4 used hand-set bounds of 8e-2 / 2e-2 / 1e-1 here)."""
     import unet_amd
+    from oracle import nn_ref as N
     from oracle import step_ref as S
+    from yardstick import Collector
     dev = _dev()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     g = torch.Generator().manual_seed(1)
@@ -108,6 +111,10 @@ def test_b8_512_logits_and_loss_against_the_cpu_oracle_directly():
     model = unet_amd.UNet(1, 1, bilinear=True)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     _, _, ref = S.train_step(state, None, images, masks, n_classes=1, bilinear=True)
+    twin = N.NNUNet(1, 1, True)
+    twin.load_state_dict(state)
+    own = N.NNStepper(twin, amp=True).step(images, masks)          # the reference's own bf16 run of this step
+    own.pop("grads")
     im_d = images.to(dev).contiguous(memory_format=torch.channels_last)
     mk_d = masks.to(dev)
     for amp in (False, True):
@@ -122,10 +129,11 @@ def test_b8_512_logits_and_loss_against_the_cpu_oracle_directly():
                 close(t[k], ref[k], 1e-4, f"fp32 {k} vs oracle")
             close(t["grad_norm"], ref["grad_norm"], 1e-3, "fp32 grad_norm vs oracle")
         else:
-            check(t["logits"].float(), ref["logits"], 8e-2, "bf16 logits vs oracle (L2)", l2=True)
-            for k in ("bce", "dice", "loss"):
-                close(t[k], ref[k], 2e-2, f"bf16 {k} vs oracle")
-            close(t["grad_norm"], ref["grad_norm"], 1e-1, "bf16 grad_norm vs oracle")
+            c = Collector("UNet 8x512x512")
+            c.tensor("logits", t["logits"].float(), ref["logits"], own["logits"])
+            for k in ("bce", "dice", "boundary", "loss", "grad_norm"):
+                c.scalar(k, float(t[k].detach()), ref[k], own[k])
+            c.done()
         st.optimizer.close()
         del st, m
 
@@ -194,6 +202,57 @@ def test_config4_at_its_real_size_1024():
     close(b16["grad_norm"], f32["grad_norm"], 2e-1, "cfg4@1024 bf16 grad_norm")
     assert torch.equal(b16["logits"], b16b["logits"]) and torch.equal(b16["params"], b16b["params"]), "not bit-deterministic"
     assert float(f32["loss"]) > 0 and float(f32["grad_norm"]) > 0
+
+
+def test_config4_at_1024_against_the_reference_graph_on_the_cpu():
+    """BASELINE configs[3] at size against a CPU answer: the reference's graph from stock torch.nn modules (oracle/nn_ref.py:
+    the depth-5 net composed as fixture G11 / G13 compose it from the reference's own unet_parts) takes the same step on the same
+    1 x 3x1024x1024 batch on the host -- 4.8 TFLOP, ten seconds on the box's cores -- in fp32 and under bf16 autocast.  HIP fp32:
+    logits at the north star's 1e-3, loss terms 1e-4 (boundary 1e-3: thresholded counts), gradient norm 2e-3.  HIP bf16: the
+    reference's own bf16 run is the yardstick (tests/yardstick.py)."""
+    import unet_amd
+    from oracle import nn_ref as N
+    from yardstick import Collector
+    dev = _dev()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g = torch.Generator().manual_seed(44)
+    im = torch.rand(1, 3, 1024, 1024, generator=g)
+    mk = torch.randint(0, 4, (1, 1024, 1024), generator=g)
+    widths = (64, 128, 256, 512, 1024, 2048)
+    torch.manual_seed(0)
+    model = unet_amd.UNetDepth(3, 4, True, widths=widths)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = {}
+    for amp in (False, True):
+        twin = N.NNUNet(3, 4, True, widths).to(memory_format=torch.channels_last)
+        twin.load_state_dict(state)
+        ref[amp] = N.NNStepper(twin, amp=amp, boundary_weight_multiclass=0.2).step(im.contiguous(memory_format=torch.channels_last), mk)
+        ref[amp].pop("grads")
+        del twin
+    im_d = im.to(dev).contiguous(memory_format=torch.channels_last)
+    mk_d = mk.to(dev)
+    for amp in (False, True):
+        m = unet_amd.UNetDepth(3, 4, True, widths=widths)
+        m.load_state_dict(state)
+        m = m.to(memory_format=torch.channels_last).to(dev)
+        st = unet_amd.TrainStepper(m, lr=1e-5, amp=amp)
+        m.train()
+        t = unet_amd.train_step(m, st.optimizer, im_d, mk_d, amp=amp, boundary_weight=0.2)
+        torch.cuda.synchronize()
+        if not amp:
+            check(t["logits"], ref[False]["logits"], 1e-3, "cfg4@1024 fp32 logits vs the CPU graph (max)")
+            for k in ("ce", "dice", "loss"):
+                close(t[k], ref[False][k], 1e-4, f"cfg4@1024 fp32 {k}")
+            close(t["boundary"], ref[False]["boundary"], 1e-3, "cfg4@1024 fp32 boundary")
+            close(t["grad_norm"], ref[False]["grad_norm"], 2e-3, "cfg4@1024 fp32 grad_norm")
+        else:
+            c = Collector("cfg4 1x3x1024x1024")
+            c.tensor("logits", t["logits"].float(), ref[False]["logits"], ref[True]["logits"])
+            for k in ("ce", "dice", "boundary", "loss", "grad_norm"):
+                c.scalar(k, float(t[k].detach()), ref[False][k], ref[True][k])
+            c.done()
+        st.optimizer.close()
+        del st, m
 
 
 # ------------------------------------------------------------------------------------------ G13: full-width config 4 / 5

@@ -160,9 +160,9 @@ def _conv_case(dtype, B, H, W, C0, C1, Cout, tol_f32=2e-5):
     ops.conv3x3_wgrad(dyg, x0, x1, dwk)
     dwn = dwk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     # inputs are exact in both; fp32: only the accumulation order differs.  bf16: the per-split partial sums travel to the reduce
-    # kernel rounded to bf16 (conv3x3_wgrad_mfma_v2<.., SLAB16>) and are added in fp32 -- 2^-9 per partial, in quadrature over the
-    # splits; the reference's autocast backward rounds the TOTAL to bf16, 2^-9 = 2e-3 of each element
-    tolw = 2e-5 if dtype == torch.float32 else 3e-3
+    # kernel as block-scaled fp16 (conv3x3_wgrad_mfma_v2<.., SLAB16>: 2^-12 per partial) and are added in fp32; the reference's
+    # autocast backward rounds the TOTAL to bf16, 2^-9 = 2e-3 of each element
+    tolw = 2e-5 if dtype == torch.float32 else 1e-3
     assert rel(dwn, dwref) < tolw, f"wgrad {rel(dwn, dwref):.3e}"
 
 
@@ -765,25 +765,56 @@ def test_default_library_refuses_the_consumer_side_batchnorm_calls_loudly():
                  ws.data_ptr(), nbytes, 2, 64, 64, UH_BF16, st)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 128, 128, 128, 256), (2, 256, 256, 64, 64), (4, 32, 32, 512, 512)])
-def test_bf16_slabs_are_no_less_precise_than_the_reference_rounding_of_the_total(B, H, W, Cin, Cout):
-    """The per-split partial sums of bf16 backward-weights travel to the reduce kernel as bf16 pairs (SLAB16) and are added in fp32.
-    The reference's autocast backward returns the filter gradient in bf16, i.e. it rounds the TOTAL (train.py:116; the conv's weight
-    is a bf16 copy).  Claim held here: against fp64, the error of this kernel's fp32 result is of the size of that single rounding
-    of the total (rms over the tensor, not above 1.25 x), and far below bf16's own step on the largest elements."""
+def _wgrad_errors(x, dy, dev):
+    """rms error of uh_conv3x3_wgrad (bf16 tensors) against fp64, rms error of the fp64 total rounded to bf16 -- what the
+    reference's autocast backward hands to the optimizer (train.py:116; the conv's weight is a bf16 copy) -- and the largest error
+    relative to the largest element."""
     from unet_amd import ops
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    wd = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (dwref,) = torch.autograd.grad(F.conv2d(x.double(), wd, padding=1), [wd], dy.double())
+    dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
+    ops.conv3x3_wgrad(_nhwc(dy, torch.bfloat16, dev), _nhwc(x, torch.bfloat16, dev), None, dwk)
+    ours = dwk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu()
+    e_ours = float((ours - dwref).pow(2).mean().sqrt())
+    e_ref = float((dwref.float().bfloat16().double() - dwref).pow(2).mean().sqrt())
+    return e_ours, e_ref, float((ours - dwref).abs().max() / dwref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 128, 128, 128, 256), (2, 256, 256, 64, 64), (4, 32, 32, 512, 512)])
+def test_16_bit_slabs_are_more_precise_than_the_reference_rounding_of_the_total(B, H, W, Cin, Cout):
+    """The per-split partial sums of bf16 backward-weights travel to the reduce kernel as block-scaled fp16 pairs (SLAB16) and are
+    added in fp32.  The reference's autocast backward returns the filter gradient in bf16, i.e. it rounds the TOTAL.  On
+    i.i.d. gradients the partials, added in quadrature, are about as large as the total, and fp16 carries three more bits than
+    bf16: the error against fp64 stays far below that single rounding of the total."""
     dev = _dev()
     g = torch.Generator().manual_seed(B + H + Cin + Cout)
     x = torch.relu(torch.randn(B, Cin, H, W, generator=g)).bfloat16().float()           # activations as the layer sees them: half zeros
     dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
-    xd = x.double()
-    wd = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
-    (dwref,) = torch.autograd.grad(F.conv2d(xd, wd, padding=1), [wd], dy.double())
-    dwk = torch.empty(Cout * 9 * Cin, dtype=torch.float32, device=dev)
-    ops.conv3x3_wgrad(_nhwc(dy, torch.bfloat16, dev), _nhwc(x, torch.bfloat16, dev), None, dwk)
-    ours = dwk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu()
-    as_reference = dwref.float().bfloat16().double()                                       # what autocast hands to the optimizer
-    e_ours = float((ours - dwref).pow(2).mean().sqrt())
-    e_ref = float((as_reference - dwref).pow(2).mean().sqrt())
-    assert e_ours <= 1.25 * e_ref, (e_ours, e_ref)
-    assert float((ours - dwref).abs().max()) <= 3e-3 * float(dwref.abs().max())
+    e_ours, e_ref, worst = _wgrad_errors(x, dy, dev)
+    assert e_ours <= 0.25 * e_ref, (e_ours, e_ref)
+    assert worst <= 5e-4, worst
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 256, 256, 64, 64), (8, 256, 256, 64, 128), (2, 128, 128, 128, 256), (4, 64, 64, 256, 512)])
+@pytest.mark.parametrize("noise", [0.0, 0.3])
+def test_16_bit_slabs_with_a_gradient_whose_sign_follows_image_regions(B, H, W, Cin, Cout, noise):
+    """i.i.d. gradients hide the hard case.  Here dy is +a inside a centred disc and -a' outside, zero-sum per
+    channel over the batch (what BatchNorm backward hands down), x is a ReLU'd activation with a large mean: a pixel tile lies
+    inside one region, so every per-split partial sum is ~10 x larger than the total in quadrature, whatever the order of the
+    tiles (contiguous ranges and strided tiles measured alike, scratch/r5_slab_structured.py).  Round 4's bf16 partials put the
+    result 8-13 x above the reference's single bf16 rounding of the total on these inputs; block-scaled fp16 must stay within
+    1.6 x of it (measured 1.0-1.5), and fp32 slabs (UH_WGRAD_SLAB_F32=1) remain for anyone who wants the partials exact."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    disc = (((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.3 * min(H, W)) ** 2).float()
+    sign = disc - (1 - disc) * disc.mean() / (1 - disc.mean())
+    amp = torch.rand(1, Cout, 1, 1, generator=g) + 0.5
+    dy = sign[None, None] * amp + noise * torch.randn(B, Cout, H, W, generator=g)
+    dy = dy - dy.mean(dim=(0, 2, 3), keepdim=True)
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g) + 1.5)
+    e_ours, e_ref, worst = _wgrad_errors(x.bfloat16().float(), dy.bfloat16().float(), dev)
+    assert e_ours <= 1.6 * e_ref, (e_ours, e_ref, e_ours / e_ref)
+    assert worst <= 6e-3, worst

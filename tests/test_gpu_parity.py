@@ -1,7 +1,8 @@
 """GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI via the
 drop-in modules, against (a) the golden fixtures produced by the reference's own modules and (b) the
 CPU oracle (oracle/) on seeded inputs.  Tolerances: fp32 path 1e-3 relative to the tensor's max
-(BASELINE.json north_star), bf16 path 3e-2 (documented: bf16 activations, fp32 accumulation)."""
+(BASELINE.json north_star); bf16 path: no hand-set tolerance -- err(HIP bf16, reference fp32) against the reference's own
+err(bf16 autocast, fp32) on the same inputs (tests/yardstick.py, tests/test_gpu_bf16_vs_reference.py)."""
 import numpy as np
 import pytest
 import torch
@@ -268,7 +269,30 @@ def _oracle_block(kind, st, xs, cot, bilinear=True, dtype=torch.float64):
     return y.detach(), grads[:len(xs)], {k[2:]: g for k, g in zip(keys, grads[len(xs):])}
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2)])
+def _bf16_block_against_the_reference_graph(tag, kind, st, xs, cot, y, dxs, named_grads, bilinear=True):
+    """bf16 leg of the block tests: the yardstick is the same block from stock torch.nn modules (oracle/nn_ref.py: the
+    reference's graph, bit-identical to fixture set G15 in both legs) run on the CPU in fp32 and under
+    torch.autocast('cpu', bfloat16) on these very inputs -- tests/yardstick.py."""
+    from oracle import nn_ref as N
+    from yardstick import Collector
+    cin_total = st[[k for k in st if k.endswith("double_conv.0.weight")][0]].shape[1]
+    cout = st[[k for k in st if k.endswith("double_conv.3.weight")][0]].shape[0]
+    if kind == "double_conv":
+        blk = N.double_conv_module(cin_total, cout)
+    else:
+        blk = N.up_module(cin_total, cout, bilinear)
+    y32, dx32, g32 = N.block_fwd_bwd(blk, st, xs, cot, amp=False)
+    y16, dx16, g16 = N.block_fwd_bwd(blk, st, xs, cot, amp=True)
+    c = Collector(tag)
+    c.tensor("y", y, y32, y16)
+    for i, dx in enumerate(dxs):
+        c.tensor(f"dx{i}", dx, dx32[i], dx16[i])
+    for k, g in named_grads.items():
+        c.tensor("grad " + k, g, g32[k], g16[k])
+    c.done()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, None)])
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 40, 56), (128, 64, 33, 17), (32, 256, 16, 16)])
 def test_double_conv_mfma_vs_oracle(dtype, tol, cin, cout, h, w):
     import unet_amd
@@ -280,25 +304,26 @@ def test_double_conv_mfma_vs_oracle(dtype, tol, cin, cout, h, w):
     x = torch.randn(2, cin, h, w)
     cot = torch.randn(2, cout, h, w)
     st = {k: v.detach().clone() for k, v in mod.state_dict().items()}
-    yo, dxo, go = _oracle_block("double_conv", st, [x], cot)
     mod = mod.to(dev).train()
     xg = x.to(dev).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
         y = mod(xg)
     y.float().backward(cot.to(dev))
-    l2 = dtype == torch.bfloat16
     tag = f"dconv{cin}-{cout} {str(dtype)[6:]} "
-    check(y.float(), yo, tol, tag + "y", l2=l2)
-    # bf16: ~0.3 % of the ReLU masks sit within bf16 round-off of zero and flip relative to the fp64
-    # oracle; each flip switches a whole term on or off, i.e. sqrt(0.003) ~ 5 % in relative L2 on the
-    # gradients (inherent to bf16 activations, also under torch autocast) -> 1e-1 L2 for bf16 gradients.
-    gt = 1e-1 if l2 else tol * 3
-    check(xg.grad, dxo[0], gt if l2 else tol * 2, tag + "dx", l2=l2)
+    if dtype == torch.bfloat16:
+        # (round 4 held these gradients to a hand-set 1e-1 relative L2 and used 0.6-0.99 of it; fixture G15 shows where that
+        # comes from: the reference's OWN bf16 gradients of such a block sit 5-9.5e-2 from its fp32 ones)
+        _bf16_block_against_the_reference_graph(tag, "double_conv", st, [x], cot, y.float(), [xg.grad],
+                                                {k: p.grad for k, p in mod.named_parameters()})
+        return
+    yo, dxo, go = _oracle_block("double_conv", st, [x], cot)
+    check(y.float(), yo, tol, tag + "y")
+    check(xg.grad, dxo[0], tol * 2, tag + "dx")
     for k, p in mod.named_parameters():
-        check(p.grad, go[k], gt, tag + "grad " + k, l2=l2)
+        check(p.grad, go[k], tol * 3, tag + "grad " + k)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, None)])
 @pytest.mark.parametrize("bilinear", [True, False])
 def test_up_mfma_two_sources_vs_oracle(dtype, tol, bilinear):
     import unet_amd
@@ -310,20 +335,22 @@ def test_up_mfma_two_sources_vs_oracle(dtype, tol, bilinear):
     x2 = torch.randn(2, 64, 25, 39)          # odd sizes: pad rule + partial tiles
     cot = torch.randn(2, 64, 25, 39)
     st = {k: v.detach().clone() for k, v in mod.state_dict().items()}
-    yo, dxo, go = _oracle_block("up", st, [x1, x2], cot, bilinear)
     mod = mod.to(dev).train()
     a, b = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
         y = mod(a, b)
     y.float().backward(cot.to(dev))
-    l2 = dtype == torch.bfloat16
     tag = f"up{'bil' if bilinear else 'ct'} {str(dtype)[6:]} "
-    check(y.float(), yo, tol, tag + "y", l2=l2)
-    gt = 1e-1 if l2 else tol * 3           # see test_double_conv_mfma_vs_oracle for the bf16 allowance
-    check(a.grad, dxo[0], gt if l2 else tol * 2, tag + "dx1", l2=l2)
-    check(b.grad, dxo[1], gt if l2 else tol * 2, tag + "dx2", l2=l2)
+    if dtype == torch.bfloat16:
+        _bf16_block_against_the_reference_graph(tag, "up", st, [x1, x2], cot, y.float(), [a.grad, b.grad],
+                                                {k: p.grad for k, p in mod.named_parameters()}, bilinear)
+        return
+    yo, dxo, go = _oracle_block("up", st, [x1, x2], cot, bilinear)
+    check(y.float(), yo, tol, tag + "y")
+    check(a.grad, dxo[0], tol * 2, tag + "dx1")
+    check(b.grad, dxo[1], tol * 2, tag + "dx2")
     for k, p in mod.named_parameters():
-        check(p.grad, go[k], gt, tag + "grad " + k, l2=l2)
+        check(p.grad, go[k], tol * 3, tag + "grad " + k)
 
 
 def test_full_unet_step_vs_oracle_fp32():
@@ -360,9 +387,13 @@ def test_full_unet_step_vs_oracle_fp32():
     assert not failures, "\n".join(failures)
 
 
-def test_full_unet_step_bf16_close_to_oracle():
+def test_full_unet_step_bf16_against_the_reference_graph_under_autocast():
+    """One bf16 step of UNet(1,1,bilinear=True) on 2x1x96x64 against the same step of the reference's graph (oracle/nn_ref.py,
+    stock torch.nn modules, stock RMSprop) in fp32, with that graph under torch.autocast('cpu', bfloat16) as the yardstick
+    (tests/yardstick.py): logits, every loss term, the gradient norm, every parameter's clipped gradient."""
     import unet_amd
-    from oracle import step_ref as S
+    from oracle import nn_ref as N
+    from yardstick import Collector
     dev = _dev()
     torch.manual_seed(0)
     model = unet_amd.UNet(1, 1, bilinear=True)
@@ -370,13 +401,21 @@ def test_full_unet_step_bf16_close_to_oracle():
     images = torch.rand(2, 1, 96, 64, generator=g)
     masks = torch.randint(0, 3, (2, 96, 64), generator=g)
     st = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    _, _, info = S.train_step(st, None, images, masks, n_classes=1, bilinear=True)
+    ref = {}
+    for amp in (False, True):
+        m = N.NNUNet(1, 1, True)
+        m.load_state_dict(st)
+        ref[amp] = N.NNStepper(m, amp=amp).step(images, masks)
     model = model.to(dev)
     stepper = unet_amd.TrainStepper(model, amp=True)
     terms = stepper.step(images.to(dev), masks.to(dev))
-    check(terms["logits"], info["logits"], 8e-2, "unet logits bf16", l2=True)
-    check(terms["loss"], info["loss"], 2e-2, "unet loss bf16")
-    check(terms["grad_norm"], info["grad_norm"], 1e-1, "unet grad_norm bf16")
+    c = Collector("UNet 96x64")
+    c.tensor("logits", terms["logits"].float(), ref[False]["logits"], ref[True]["logits"])
+    for q in ("bce", "dice", "boundary", "loss", "grad_norm"):
+        c.scalar(q, float(terms[q].detach()), ref[False][q], ref[True][q])
+    for k, p in model.named_parameters():
+        c.tensor("grad " + k, stepper.optimizer.grad_of(p), ref[False]["grads"][k], ref[True]["grads"][k])
+    c.done()
 
 
 def test_missing_gpu_tensor_fails_loudly():
@@ -424,6 +463,10 @@ def test_dice_after_training_matches_oracle():
         assert abs(r[name + "_avg"] - r["ref_cpu_fp32_avg"]) < 0.02, (name, r)
         assert abs(r[name] - r["ref_cpu_fp32"]) < 0.02, (name, r)
         assert min(r[name + "_avg_runs"]) >= min(r["ref_cpu_fp32_avg_runs"]) - 0.15, (name, r)
+    # like for like: the HIP bf16 runs beside the reference's OWN bf16 runs (the torch.nn graph under torch.autocast('cpu',
+    # bfloat16), train.py:116) from the same five initialisations -- medians within 0.03, worst run no more than 0.15 below theirs
+    assert abs(r["hip_bf16_avg"] - r["ref_cpu_bf16_avg"]) < 0.03, r
+    assert min(r["hip_bf16_avg_runs"]) >= min(r["ref_cpu_bf16_avg_runs"]) - 0.15, r
 
 
 @pytest.mark.parametrize("B,H,W,scale,w_b", [

@@ -1926,6 +1926,13 @@ static bool uh_no_wres() {
 // statistics / partial rows written) it is launched with.  Mirrors the branches of conv3x3_fwd_dispatch below.
 // K split inside the workgroup (KS = 2, see the kernel): bf16, 16 channels per wave, at most one (tile, 64-channel slab) pair
 // per CU and an even number (>= 8) of 32-channel K-chunks.  UH_NO_KSPLIT=1 turns it off (A/B runs).
+// UH_WRES_WIDE=1 (experiment, round 5): 64 input channels and 128+ output channels (down1.0 forward, backward-data of up4.0 / up3.3)
+// take the register-resident-filter form, one launch of 64-channel slabs, instead of the 32-channel-per-wave streaming form
+static bool uh_wres_wide() {
+    static const bool on = getenv("UH_WRES_WIDE") != nullptr && getenv("UH_WRES_WIDE")[0] == '1';
+    return on;
+}
+
 static bool fwd_ksplit_ok(int ntile, int Cin, int Cout) {
     static const bool off = getenv("UH_NO_KSPLIT") != nullptr && getenv("UH_NO_KSPLIT")[0] == '1';
     const int nchunk = Cin / 32;
@@ -1941,7 +1948,8 @@ static FwdSel fwd_select(int ntile, int Cin, int Cout, bool bf16_plain, bool bsu
     };
     FwdSel r;
     r.ks = 1;
-    if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) { r.nbw = 2; r.wres = false; r.slabs = Cout / 128; r.gx = lanes_for(2, r.slabs); }
+    const bool wres_first = bf16_plain && Cin == 64 && !uh_no_wres() && uh_wres_wide();
+    if (!wres_first && Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) { r.nbw = 2; r.wres = false; r.slabs = Cout / 128; r.gx = lanes_for(2, r.slabs); }
     else if (bf16_plain && Cin == 64 && !uh_no_wres()) { r.nbw = 1; r.wres = true; r.slabs = Cout / 64; r.gx = lanes_for(2, r.slabs); }
     else {
         r.nbw = 1; r.wres = false; r.slabs = Cout / 64; r.gx = lanes_for(bsum ? 2 : 3, r.slabs);
@@ -2053,7 +2061,8 @@ static int conv3x3_fwd_dispatch(const T* x0, int C0, int ld0, const T* x1, int C
                     return UH_EINVAL;
                 }
             }
-            if (Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
+            const bool wres_first = ES == 2 && !split && !narrow && C0 + C1 == 2 * CK && !uh_no_wres() && uh_wres_wide();
+            if (!wres_first && Cout % 128 == 0 && (int64_t)ntile * (Cout / 128) >= 512) {
                 int slabs = Cout / 128, gx = lanes_for(2, slabs);
                 if (split) {
                     if constexpr (CAN_SPLIT)
@@ -2617,27 +2626,44 @@ __global__ __launch_bounds__(256) void slab_reduce_tall_kernel(const float* __re
     if (threadIdx.x < 4 && i4 < n4) reinterpret_cast<f32x4*>(out)[i4] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
-// The same for slabs of bf16 pairs (conv3x3_wgrad_mfma_v2<.., SLAB16>): dword (cp, tap, ci) of a slab = rows 2 cp, 2 cp + 1 of one
-// (tap, ci).  npair = (Cout / 2) * row dwords per slab, row = 9 * Cin (a multiple of 4: a 16-byte piece stays inside one row pair).
-__device__ __forceinline__ void slab_reduce_block_bf16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
-                                                           int64_t npair, int row, int nsplit, int64_t blk, f32x4 (*red)[64]) {
+// The same for slabs of block-scaled fp16 pairs (conv3x3_wgrad_mfma_v2<.., SLAB16>): dword (cp, tap, ci) of a slab = rows 2 cp,
+// 2 cp + 1 of one (tap, ci) as fp16 values v * 2^s, with ONE power-of-two scale per (split, workgroup block of coblk x 64 filter
+// rows / input channels); the inverse scales [nsplit][nby] (nby = (Cout / coblk) * (Cin / 64), block = cot * (Cin / 64) + cit) sit
+// behind the slabs.  npair = (Cout / 2) * row dwords per slab, row = 9 * Cin (a multiple of 4: a 16-byte piece stays inside one
+// row pair and one 64-channel block).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
+                                                          int64_t npair, int row, int nsplit, int coblk, int64_t blk,
+                                                          f32x4 (*red)[64]) {
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i4 = blk * 64 + cl;
     const int64_t n4 = npair >> 2;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo, lo2 = lo, hi2 = lo;
-    auto add = [](f32x4& l, f32x4& h, const u32x4 v) {
+    auto add = [](f32x4& l, f32x4& h, const u32x4 v, const float sc) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { l[e] += __uint_as_float(v[e] << 16); h[e] += __uint_as_float(v[e] & 0xffff0000u); }
+        for (int e = 0; e < 4; ++e) {
+            const f16x2 p = __builtin_bit_cast(f16x2, v[e]);
+            l[e] = fmaf((float)p[0], sc, l[e]);            // (a power of two: the product is exact, the fma rounds the sum once)
+            h[e] = fmaf((float)p[1], sc, h[e]);
+        }
     };
+    const int64_t e0 = (i4 < n4 ? i4 : 0) << 2;           // first dword of the piece
+    const int64_t cp = e0 / row, rem = e0 - cp * row;
     if (i4 < n4) {
+        const int Cin = row / 9, nci = Cin >> 6;
+        const int tap = (int)(rem / Cin), ci = (int)(rem - (int64_t)tap * Cin);
+        const int nby = nci * (int)((npair * 2 / row) / coblk);
+        const float* scales = reinterpret_cast<const float*>(slabs + (int64_t)nsplit * npair) + ((int)(2 * cp) / coblk) * nci + (ci >> 6);
         const u32x4* base = reinterpret_cast<const u32x4*>(slabs) + i4;
         int k = sl;
         for (; k + 12 < nsplit; k += 16) {           // four independent loads in flight per lane, added in a fixed order
             const u32x4 v0 = base[(int64_t)k * n4], v1 = base[(int64_t)(k + 4) * n4];
             const u32x4 v2 = base[(int64_t)(k + 8) * n4], v3 = base[(int64_t)(k + 12) * n4];
-            add(lo, hi, v0); add(lo2, hi2, v1); add(lo, hi, v2); add(lo2, hi2, v3);
+            const float s0 = scales[(int64_t)k * nby], s1 = scales[(int64_t)(k + 4) * nby];
+            const float s2 = scales[(int64_t)(k + 8) * nby], s3 = scales[(int64_t)(k + 12) * nby];
+            add(lo, hi, v0, s0); add(lo2, hi2, v1, s1); add(lo, hi, v2, s2); add(lo2, hi2, v3, s3);
         }
-        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4]);
+        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4], scales[(int64_t)k * nby]);
     }
     red[sl][cl] = lo + lo2;
     red[4 + sl][cl] = hi + hi2;
@@ -2645,21 +2671,19 @@ __device__ __forceinline__ void slab_reduce_block_bf16pair(const unsigned* __res
     if (sl < 2 && i4 < n4) {                          // split lane 0 writes the even rows, lane 1 the odd ones
         const int o = 4 * sl;
         const f32x4 v = (red[o][cl] + red[o + 1][cl]) + (red[o + 2][cl] + red[o + 3][cl]);
-        const int64_t e = i4 << 2;                    // first dword of the piece
-        const int64_t cp = e / row, rem = e - cp * row;
         *reinterpret_cast<f32x4*>(out + (2 * cp + sl) * row + rem) = v;
     }
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_bf16pair_kernel(const unsigned* __restrict__ slabs, float* __restrict__ out,
-                                                                   int64_t npair, int row, int nsplit) {
+__global__ __launch_bounds__(256) void slab_reduce_f16pair_kernel(const unsigned* __restrict__ slabs, float* __restrict__ out,
+                                                                  int64_t npair, int row, int nsplit, int coblk) {
     __shared__ f32x4 red[8][64];
-    slab_reduce_block_bf16pair(slabs, out, npair, row, nsplit, blockIdx.x, red);
+    slab_reduce_block_f16pair(slabs, out, npair, row, nsplit, coblk, blockIdx.x, red);
 }
 
 // Every pending slab reduction of a backward pass in ONE launch (uh_slab_reduce_batched): the filter gradients only feed the
 // optimizer, so the per-layer reduce launches -- eighteen 8-14 us kernels in the middle of the backward stream -- can wait until
-// the gradients are needed.  table[r] = { slabs, out, n, nsplit, format (0 fp32, 1 bf16 pairs), row, first block, 0 } (int64).
+// the gradients are needed.  table[r] = { slabs, out, n, nsplit, format (0 fp32, 1 scaled fp16 pairs), row, first block, coblk } (int64).
 constexpr int SLAB_TAB = 8;
 __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t* __restrict__ table, int nrows) {
     __shared__ f32x4 red[8][64];
@@ -2672,8 +2696,8 @@ __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t*
     if (t[4] == 0)
         slab_reduce_block_f32(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[2], (int)t[3], blk, red);
     else
-        slab_reduce_block_bf16pair(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]), t[2] / 2, (int)t[5],
-                                   (int)t[3], blk, red);
+        slab_reduce_block_f16pair(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]), t[2] / 2, (int)t[5],
+                                  (int)t[3], (int)t[7], blk, red);
 }
 
 // =====================================================================================
@@ -2691,17 +2715,22 @@ __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t*
 // front of the tile's barrier.  LDS is full (two workgroups x two stages = 160 KiB), so the 64 (scale, shift) pairs of the
 // workgroup's input-channel slab live in ONE register pair spread over the lanes (lane = channel) and reach the lane that needs
 // them through ds_bpermute (the LDS crossbar, no LDS memory).
-// SLAB16: the per-split partial results go to the workspace as bf16 PAIRS (u32 = rows co, co + 1 of one (tap, ci)) instead of fp32:
-// half the 75 MB a launch writes and slab_reduce reads back.  Each partial is a sum over >= one tile of pixels accumulated in
-// fp32 by the MFMAs and rounded ONCE; slab_reduce adds the rounded partials in fp32 and the result stays fp32.  The reference
-// (train.py:116 autocast) rounds the TOTAL to bf16 -- conv backward returns the filter gradient in the dtype of the bf16 filter
-// copy -- so its error per element, 2^-9 |total|, is the error of nsplit rounded partials of random sign added in quadrature
-// and larger than ours when the partials agree in sign.  fp32 slabs: UH_WGRAD_SLAB_F32=1.
+// SLAB16: the per-split partial results go to the workspace as 16-bit PAIRS (u32 = rows co, co + 1 of one (tap, ci)) instead of
+// fp32: half the 75 MB a launch writes and slab_reduce reads back.  Each partial is a sum over >= one tile of pixels accumulated
+// in fp32 by the MFMAs and rounded ONCE, to fp16 (11 significant bits, rms relative error 2^-12.8) after multiplication by a power
+// of two chosen per workgroup so that its largest |value| lands in [2^14, 2^15): block-scaled fp16.  slab_reduce multiplies back
+// and adds in fp32; the result stays fp32.  (Round 4 stored bf16: 8 significant bits.  The partials of a filter gradient can be
+// an order of magnitude larger than their sum -- a gradient whose sign follows image regions sums to zero over the batch after
+// BatchNorm backward, while a tile lies inside one region -- and the error then was that much above the single bf16 rounding of
+// the TOTAL the reference's autocast backward performs (train.py:116; conv backward returns the filter gradient in the dtype of
+// the bf16 filter copy): 8-13 x on synthetic region-signed gradients, up to 2.7 x on one layer of a trained UNet, 0.1-0.9 x
+// elsewhere (scratch/r5_slab_structured.py).  Three more bits put all of them at or below the reference's own rounding.)
+// fp32 slabs: UH_WGRAD_SLAB_F32=1.
 template <typename T, int NWR, bool PRE = false, bool SLAB16 = false>
 __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1,
     int ld1, float* __restrict__ slabs, int Cout, int B, int H, int W, int tilesX, int tilesY, int nsplit,
-    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv, int strided, const float* __restrict__ pre_scale = nullptr,
+    unsigned dy_bytes, unsigned x_bytes, int C0v, int C1v, int Coutv, const float* __restrict__ pre_scale = nullptr,
     const float* __restrict__ pre_shift = nullptr) {
     static_assert(sizeof(T) == 2, "v2 is the bf16 kernel");
     constexpr int TH = 8;
@@ -2737,13 +2766,8 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
 
     const int ntile = B * tilesX * tilesY;
     const int split = blockIdx.x;
-    // strided != 0 (default): split s owns tiles s, s + nsplit, s + 2 nsplit, ... -- every partial sum then samples the whole batch
-    // extent instead of one contiguous range of tile rows, so that a gradient whose SIGN follows image regions (foreground against
-    // background: after BatchNorm backward it sums to zero over the batch) cancels inside the fp32 accumulators, not between
-    // partials that were rounded to bf16 on the way to the reduce kernel (SLAB16); strided == 0: contiguous ranges (UH_WGRAD_CONTIG=1)
-    const int tstep = strided ? nsplit : 1;
-    const int t_begin = strided ? split : (int)(((int64_t)ntile * split) / nsplit);
-    const int t_end = strided ? ntile : (int)(((int64_t)ntile * (split + 1)) / nsplit);
+    const int t_begin = (int)(((int64_t)ntile * split) / nsplit);
+    const int t_end = (int)(((int64_t)ntile * (split + 1)) / nsplit);
 
     // per-thread DMA geometry that does not depend on the tile: halo coordinates of each 16-byte unit and its byte
     // offset relative to the tile's top-left halo pixel (tile-dependent part is one scalar base + 4 range checks)
@@ -2983,14 +3007,14 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     ld_d(lds + XBYTES, 0);
     ld_x(lds, 0);
     int bufi = 0;
-    for (int tile = t_begin; tile < t_end; tile += tstep, bufi ^= 1) {
+    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
         const unsigned char* xs = lds + bufi * STAGE;
         const unsigned char* ds = xs + XBYTES;
         // the next tile's DMA, into the buffer the last fence released (behind this tile's first fragment reads, which were
         // issued in front of pair 5 of the previous tile; issuing it there as well -- with pair 5's fragments still live --
         // spilled ~30 registers into the MFMA stream)
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 5; ++a) {
@@ -3000,7 +3024,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
             mma_pair(a);
         }
         // every LDS read of this tile has been issued (pair 5's in front of pair 4's MFMAs)
-        tile_fence(tile + tstep, bufi ^ 1, tile + tstep < t_end);
+        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
         {
             // (unconditional: behind the last tile these sixteen reads fetch stale LDS contents nobody uses -- a branch here
             // makes the fragments phi nodes of the loop and costs ~20 spilled registers around the fence)
@@ -3017,9 +3041,9 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
     if (t_begin < t_end) issue(t_begin, 0);
     tile_fence(t_begin, 0, t_begin < t_end);
     int bufi = 0;
-    for (int tile = t_begin; tile < t_end; tile += tstep, bufi ^= 1) {
+    for (int tile = t_begin; tile < t_end; ++tile, bufi ^= 1) {
 #if !UH_WGRAD_M16
-        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #endif
         const unsigned char* xs = lds + bufi * STAGE;
@@ -3047,7 +3071,7 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
         // released from the barrier and the matrix pipe empty; now it runs under the LDS latency of the reads the first MFMAs wait
         // for (profiles/r03_wgrad_phase_stamps.txt).  The buffer it writes was released by the barrier at the end of the last tile.
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + tstep < t_end) issue(tile + tstep, bufi ^ 1);
+        if (tile + 1 < t_end) issue(tile + 1, bufi ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -3094,14 +3118,41 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
                         acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[hy - r], xfr[hy][s], acc[r * 3 + s], 0, 0, 0);
         }
 #endif
-        tile_fence(tile + tstep, bufi ^ 1, tile + tstep < t_end);
+        tile_fence(tile + 1, bufi ^ 1, tile + 1 < t_end);
     }
     }
 
 #if UH_WGRAD_M16
     if constexpr (SLAB16) {
-        // [co / 2][tap][ci] dwords: low half = row co (even), high half = row co + 1; a lane's accumulators j, j + 1 are such a pair
+        // ---- the workgroup's largest |partial| -> one power-of-two scale (the tile loop is over: LDS is scratch now; the only LDS
+        // operations still in flight are the rotated loop's look-ahead reads, whose results nobody uses)
+        float m = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(acc[tap][h][hh][j]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float* wmax = reinterpret_cast<float*>(lds);
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2 * NWR; ++k) m = fmaxf(m, wmax[k]);
+        // biased exponent eb of the maximum, kept inside [15, 254] (zero / denormal maxima and infinities included): the values are
+        // multiplied by 2^(14 - (eb - 127)), the reduce kernel multiplies by 2^(eb - 127 - 14).  A NaN partial stays a NaN.
+        unsigned eb = (__float_as_uint(m) >> 23) & 0xffu;
+        eb = eb < 15u ? 15u : (eb > 254u ? 254u : eb);
+        const float sc = __uint_as_float((268u - eb) << 23);
         unsigned* slab16 = reinterpret_cast<unsigned*>(slabs) + (int64_t)split * (Cout / 2) * 9 * Cin;
+        if (tid == 0) {
+            float* inv = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(slabs) + (int64_t)nsplit * (Cout / 2) * 9 * Cin);
+            inv[(int64_t)split * gridDim.y + blockIdx.y] = __uint_as_float((eb - 14u) << 23);
+        }
+        // [co / 2][tap][ci] dwords: low half = row co (even), high half = row co + 1; a lane's accumulators j, j + 1 are such a pair
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -3112,9 +3163,8 @@ __global__ __launch_bounds__(128 * NWR, 2) void conv3x3_wgrad_mfma_v2(
                     for (int jp = 0; jp < 4; jp += 2) {
                         const int co = co0 + wr * 32 + h * 16 + (lane >> 4) * 4 + jp;
                         const int ci = ci0 + wc * 32 + hh * 16 + (lane & 15);
-                        const unsigned lo = __builtin_bit_cast(unsigned short, (bf16_t)acc[tap][h][hh][jp]);
-                        const unsigned hi = __builtin_bit_cast(unsigned short, (bf16_t)acc[tap][h][hh][jp + 1]);
-                        slab16[((int64_t)(co >> 1) * 9 + tap) * Cin + ci] = lo | (hi << 16);
+                        const f16x2 pr = {(_Float16)(acc[tap][h][hh][jp] * sc), (_Float16)(acc[tap][h][hh][jp + 1] * sc)};
+                        slab16[((int64_t)(co >> 1) * 9 + tap) * Cin + ci] = __builtin_bit_cast(unsigned, pr);
                     }
         return;
     }
@@ -3526,9 +3576,9 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
         return UH_EWORKSPACE;
     }
     float* slabs = (float*)ws;
-    // bf16-pair slabs: the bf16 LDS-DMA kernel's default (see SLAB16)
+    // block-scaled fp16-pair slabs: the bf16 LDS-DMA kernel's default (see SLAB16); the inverse scales follow the slabs in `ws`
+    // (nsplit * n * 2 + nsplit * blocks * 4 bytes <= the nsplit * n * 4 the workspace is sized for)
     static const bool slab_f32 = getenv("UH_WGRAD_SLAB_F32") != nullptr && getenv("UH_WGRAD_SLAB_F32")[0] == '1';
-    static const int strided = (getenv("UH_WGRAD_CONTIG") != nullptr && getenv("UH_WGRAD_CONTIG")[0] == '1') ? 0 : 1;
     const bool slab16 = ES == 2 && p.kind == 0 && dma && !slab_f32 && UH_WGRAD_M16 && uh_aligned16(dw);
     if (p.kind == 0) {
         const int64_t npx = (int64_t)B * H * W;
@@ -3540,7 +3590,7 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
 #define UH_LAUNCH_WGRAD_V2(NWR_, PRE_, S16_)                                                                                      \
     hipLaunchKernelGGL((conv3x3_wgrad_mfma_v2<T, NWR_, PRE_, S16_>), dim3(p.nsplit, (Cin / 64) * (Cout / (32 * NWR_))),           \
                        dim3(128 * NWR_), 0, st, dy, lddy, x0, C0, ld0, x1, C1, ld1, slabs, Cout, B, H, W, p.tilesX, p.tilesY,      \
-                       p.nsplit, db, xb, C0v, C1v, Coutv, strided, pre_scale, pre_shift)
+                       p.nsplit, db, xb, C0v, C1v, Coutv, pre_scale, pre_shift)
 #if UH_BUILD_PRE
                 if (pre) {
                     if (p.nwr == 4) { if (slab16) UH_LAUNCH_WGRAD_V2(4, true, true); else UH_LAUNCH_WGRAD_V2(4, true, false); }
@@ -3589,15 +3639,15 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     int64_t n = (int64_t)Cout * 9 * Cin;      // multiple of 4 on every slab path (Cout % 64 == 0 or 9*... stem: Cout*9*Cin)
     if (defer && n % 4 == 0 && uh_aligned16(dw) && uh_aligned16(slabs)) {
         defer[0] = (int64_t)(uintptr_t)slabs; defer[1] = (int64_t)(uintptr_t)dw; defer[2] = n; defer[3] = p.nsplit;
-        defer[4] = slab16 ? 1 : 0; defer[5] = 9 * Cin;
+        defer[4] = slab16 ? 1 : 0; defer[5] = 9 * Cin; defer[7] = 32 * p.nwr;
         defer[6] = slab16 ? (n / 2 / 4 + 63) / 64 : (n / 4 + 63) / 64;      // blocks of the reduction (the caller turns it into an offset)
         return UH_OK;
     }
     if (slab16) {
         const int64_t npair = n / 2;
-        hipLaunchKernelGGL(slab_reduce_bf16pair_kernel, dim3((unsigned)((npair / 4 + 63) / 64)), dim3(256), 0, st,
-                           (const unsigned*)slabs, dw, npair, 9 * Cin, p.nsplit);
-        UH_CHECK_LAUNCH("slab_reduce_bf16pair_kernel");
+        hipLaunchKernelGGL(slab_reduce_f16pair_kernel, dim3((unsigned)((npair / 4 + 63) / 64)), dim3(256), 0, st,
+                           (const unsigned*)slabs, dw, npair, 9 * Cin, p.nsplit, 32 * p.nwr);
+        UH_CHECK_LAUNCH("slab_reduce_f16pair_kernel");
         return UH_OK;
     }
     if (n % 4 != 0 || !uh_aligned16(dw) || !uh_aligned16(slabs))

@@ -63,8 +63,42 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     }
 }
 
+// mask / mask_div as the reference's `true_masks //= 2` leaves it for the class indices a mask holds (train.py:119).  A 64-bit
+// integer division is ~100 instructions on this chip and these kernels are instruction-bound (2 M elements, a few bytes each):
+// values in [0, 2^31) -- every real mask -- take a shift (divisor 2) or a 32-bit division; anything else the full division.
+__device__ __forceinline__ float uh_mask_quot(int64_t m, int mask_div) {
+    if ((uint64_t)m < (1ull << 31)) {
+        const int v = (int)m;
+        return (float)(mask_div == 2 ? (v >> 1) : (mask_div == 1 ? v : v / mask_div));
+    }
+    return (float)(m / mask_div);
+}
 __device__ __forceinline__ float bin_target(const int64_t* mask, int mask_div, const float* tf, int64_t i) {
-    return mask ? (float)(mask[i] / mask_div) : tf[i];
+    return mask ? uh_mask_quot(mask[i], mask_div) : tf[i];
+}
+
+// K column sums at once, each with column_sum_256's own association (thread t adds rows t, t + 256, ... in order, then the same
+// binary tree over the 256 threads): bit-identical to K calls, one set of barriers instead of K.  red: K * 256 doubles.
+template <int K>
+__device__ __forceinline__ void column_sums_256(const float* __restrict__ partials, int nblk, int k0, double* red, double (&out)[K]) {
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[k] += (double)partials[(int64_t)b * LOSS_ROW + k0 + k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k * 256 + threadIdx.x] = s[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + o];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = red[k * 256];
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------ binary path
@@ -358,6 +392,7 @@ __global__ __launch_bounds__(256) void boundary_minmax_kernel(const float* __res
 
 // target: float [B][H][W], or (mask != NULL) the int64 class-index mask itself with target = mask / mask_div -- what
 // train.py:119 / 134 hands to boundary_loss -- so that no float copy of the mask has to be made
+template <typename IDX>
 __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __restrict__ pred, int64_t pstride, int64_t bstride,
                                                              const float* __restrict__ target, const int64_t* __restrict__ mask,
                                                              int mask_div, int B, BRegion g,
@@ -379,8 +414,9 @@ __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __rest
     const float gmn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
     const float gmx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
     const bool sig = (gmn < -10.f || gmx > 10.f);         // boundary_loss.py:28
+    // IDX = int when B * H * W (and the launch's stride past it) fits 31 bits: the per-pixel div / mod chain in 32-bit arithmetic
     const int HW = g.H * g.W;
-    const int64_t n = (int64_t)B * HW;
+    const IDX n = (IDX)B * HW;
     // thresholded prediction / target at (b, linear r)
     auto pbin = [&](int64_t b, int r) -> float {
         float v = pred[b * bstride + (int64_t)r * pstride];
@@ -388,13 +424,14 @@ __global__ __launch_bounds__(256) void boundary_count_kernel(const float* __rest
         return v > 0.5f ? 1.f : 0.f;
     };
     auto tbin = [&](int64_t b, int r) -> float {                                                      // boundary_loss.py:37
-        if (mask) return (float)(mask[b * HW + r] / mask_div) == 255.f ? 1.f : 0.f;
+        if (mask) return uh_mask_quot(mask[b * HW + r], mask_div) == 255.f ? 1.f : 0.f;
         return target[b * HW + r] == 255.f ? 1.f : 0.f;
     };
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // {inter, psum, tsum} x {interior, edge}
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t b = i / HW;
-        int r = (int)(i - b * HW);
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (IDX)gridDim.x * blockDim.x) {
+        const IDX bq = i / HW;
+        const int64_t b = bq;
+        int r = (int)(i - bq * HW);
         int h = r / g.W, w = r - h * g.W;
         bool edge = g.interior_empty ? true : b_is_edge(g, h, w);
         if (g.ew == 0) edge = false;
@@ -476,8 +513,12 @@ static int boundary_loss_impl(const float* pred, int64_t pstride, int64_t bstrid
     int nmm = nblk < 512 ? nblk : 512;
     hipLaunchKernelGGL(boundary_minmax_kernel, dim3(nmm), dim3(256), 0, st, pred, pstride, n, H * W, bstride, mmbuf);
     UH_CHECK_LAUNCH("boundary_minmax_kernel");
-    hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, mask, mask_div, B, g,
-                       (const float*)mmbuf, nmm, 2, partials);
+    if (n + (int64_t)nblk * 256 < (1ll << 31))
+        hipLaunchKernelGGL(boundary_count_kernel<int>, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, mask, mask_div, B, g,
+                           (const float*)mmbuf, nmm, 2, partials);
+    else
+        hipLaunchKernelGGL(boundary_count_kernel<int64_t>, dim3(nblk), dim3(256), 0, st, pred, pstride, bstride, target, mask, mask_div, B, g,
+                           (const float*)mmbuf, nmm, 2, partials);
     UH_CHECK_LAUNCH("boundary_count_kernel");
     hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nblk, B, g, edge_weight,
                        smooth, out);
@@ -555,7 +596,7 @@ __global__ __launch_bounds__(256) void bce_dice_mm_sums_kernel(const float* __re
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float x = logits[i];
-        float t = (float)(mask[i] / mask_div);
+        float t = uh_mask_quot(mask[i], mask_div);
         float e = expf(-fabsf(x));
         float sp = log1pf(e);
         float s = (x >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
@@ -582,12 +623,15 @@ __global__ __launch_bounds__(256) void seg_loss_fused_finish_kernel(const float*
                                                                     int nblk, int B, BRegion g, float edge_weight, float smooth,
                                                                     float w_boundary, float inv_n, float* __restrict__ sums,
                                                                     float* __restrict__ out) {
-    __shared__ double red[256];
+    __shared__ double red[6 * 256];
     float fs[4];
-    for (int k = 0; k < 4; ++k) fs[k] = (float)column_sum_256(pa, nblk, k, red);
+    {
+        double d[4];
+        column_sums_256<4>(pa, nblk, 0, red, d);
+        for (int k = 0; k < 4; ++k) fs[k] = (float)d[k];
+    }
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (pb)
-        for (int k = 0; k < 6; ++k) s[k] = column_sum_256(pb, nblk, k, red);
+    if (pb) column_sums_256<6>(pb, nblk, 0, red, s);
     if (threadIdx.x != 0) return;
     float bl = 0.f;
     if (pb) {
@@ -637,8 +681,12 @@ extern "C" int uh_seg_loss_binary_fused(const float* logits, const int64_t* mask
     UH_CHECK_LAUNCH("bce_dice_mm_sums_kernel");
     const bool with_boundary = w_boundary != 0.f;
     if (with_boundary) {
-        hipLaunchKernelGGL(boundary_count_kernel, dim3(nblk), dim3(256), 0, st, logits, (int64_t)1, (int64_t)H * W, (const float*)nullptr,
-                           mask, mask_div, B, g, (const float*)(pa + 4), nblk, LOSS_ROW, pb);
+        if (n + (int64_t)nblk * 256 < (1ll << 31))
+            hipLaunchKernelGGL(boundary_count_kernel<int>, dim3(nblk), dim3(256), 0, st, logits, (int64_t)1, (int64_t)H * W, (const float*)nullptr,
+                               mask, mask_div, B, g, (const float*)(pa + 4), nblk, LOSS_ROW, pb);
+        else
+            hipLaunchKernelGGL(boundary_count_kernel<int64_t>, dim3(nblk), dim3(256), 0, st, logits, (int64_t)1, (int64_t)H * W, (const float*)nullptr,
+                               mask, mask_div, B, g, (const float*)(pa + 4), nblk, LOSS_ROW, pb);
         UH_CHECK_LAUNCH("boundary_count_kernel");
     }
     hipLaunchKernelGGL(seg_loss_fused_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)pa,

@@ -340,16 +340,16 @@ class SlabBatch:
 
     def __init__(self, flush_bytes: Optional[int] = None):
         self.flush_bytes = flush_bytes
-        self.arena = {}
+        self.arena = {}                      # one workspace per destination, kept between steps (up to ~37 MB each: close() frees them)
         self.rows, self.callbacks = [], []
         self.pending_bytes = 0
-        self._table_key = None
-        self._table = None
+        self._tables = {}                    # row set -> (device table, rows, blocks); data parallel flushes one set per bucket
 
     def workspace(self, key, nbytes: int, device) -> torch.Tensor:
         ws = self.arena.get(key)
         if ws is None or ws.numel() < nbytes or ws.device != device:
             ws = self.arena[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._tables.clear()             # a table holds workspace addresses
         return ws
 
     def add(self, desc, callback):
@@ -362,20 +362,31 @@ class SlabBatch:
     def reset(self):
         self.rows, self.callbacks, self.pending_bytes = [], [], 0
 
+    def close(self):
+        """Drop the workspaces and the device tables (the next use allocates them again)."""
+        self.reset()
+        self.arena.clear()
+        self._tables.clear()
+
     def flush(self):
         if not self.rows:
             return
         key = tuple(self.rows)
-        if key != self._table_key:
-            # (same layers, same buffers every step: the table is uploaded once; a captured graph replays with it)
+        entry = self._tables.get(key)
+        if entry is None:
+            # (same layers, same buffers every step: a table is uploaded once per row set -- through pinned memory, without
+            # blocking the host in the middle of backward -- and a captured graph replays with it)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("SlabBatch: the reduction table would be built (allocation + host-to-device copy) during graph "
+                                   "capture; run one eager step first")
             tab, off = [], 0
             for r in self.rows:
-                tab.append([r[0], r[1], r[2], r[3], r[4], r[5], off, 0])
+                tab.append([r[0], r[1], r[2], r[3], r[4], r[5], off, r[7]])
                 off += r[6]
             dev = next(iter(self.arena.values())).device
-            self._table = (torch.tensor(tab, dtype=torch.int64).to(dev), len(tab), off)
-            self._table_key = key
-        table, nrows, blocks = self._table
+            host = torch.tensor(tab, dtype=torch.int64).pin_memory()
+            entry = self._tables[key] = (host.to(dev, non_blocking=True), len(tab), off, host)     # (host kept until the copy has run)
+        table, nrows, blocks = entry[:3]
         with _Timed("slab_reduce_batched", 0.0):
             LIB.call("uh_slab_reduce_batched", table.data_ptr(), nrows, blocks, _stream())
         cbs = self.callbacks
