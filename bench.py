@@ -418,7 +418,9 @@ def main():
 
     # ---- N > 1: the fixed-global-batch leg (BASELINE config 3 = 32 images over the ranks) beside the weak headline
     strong_gb32 = None
-    if world > 1 and not strong and not args.config4 and 32 % world == 0 and not args.no_strong_leg:
+    # (N = 1 runs it too -- 32 images on the one GPU -- so that the 1 -> N scaling of the fixed global batch, the north star's
+    # ">= 6x at batch 32 x 512 x 512", is the ratio of two `strong_gb32.images_per_sec` figures measured the same way)
+    if not strong and not args.config4 and 32 % world == 0 and not args.no_strong_leg and not args.graph and B == 8:
         b2 = 32 // world
         im2, mk2 = make_batch(b2, 101 + rank)
         dt2, ex2, _ = measure(im2, mk2, args.steps, max(2, args.warmup))
@@ -623,9 +625,18 @@ def main():
             out["per_gpu_batch4"] = per_gpu_batch4
         if world > 1:
             import torch.distributed as dist
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:
+                rccl = repr(e)
             out["collective"] = {
-                "backend": dist.get_backend(), "world": dist.get_world_size(),
+                "backend": dist.get_backend(), "world": dist.get_world_size(), "rccl_version": rccl,
+                "per_gpu_batch": B, "global_batch": B * world,
                 "grad_bytes": int(stepper.optimizer.flat_g.numel() * 4), "grad_buckets": len(sync.buckets),
+                "bucket_bytes": [int((e - s_) * 4) for s_, e in sync.buckets],
+                "allreduce": "SUM of the flat fp32 gradient, one async all_reduce per bucket in backward-ready order from a stream of its own",
+                "sync_bn": (None if not args.sync_bn else
+                            ("own communicator (UH_SYNCBN_OWN_GROUP=1)" if stepper.bn_group is not None else "gradient communicator")),
                 # time the launch stream spent waiting for the gradient all-reduce in front of clip + RMSprop (two events
                 # around the waits, nothing else between them): what the overlap with the encoder backward did NOT hide
                 **exposed_stats(exposed),

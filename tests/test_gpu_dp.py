@@ -352,18 +352,19 @@ def _stale_pattern_worker(rank, world, port, q, mode):
         model = unet_amd.UNet_T(1, 1, bilinear=True).to(dev)
         opt = unet_amd.FusedRMSprop(model.parameters(), lr=1e-4)
         assert opt.sync is not None
+        reduce_sums = unet_amd.dp.make_sum_reducer(None)
         frozen = model.up2.conv.double_conv[4].weight            # a BatchNorm gamma: its gradient goes through the accumulate hook
         im, mk = unet_amd.ellipse_batch(4, 64, seed=5)
         im, mk = im[rank * 2:rank * 2 + 2].to(dev), mk[rank * 2:rank * 2 + 2].to(dev)
         err = None
-        for step in range(2):
-            # mode "rank": the parameter is frozen on rank 1 only, from the first step; mode "later": on both ranks, from step 1
-            frozen.requires_grad_(not ((mode == "rank" and rank == 1) or (mode == "later" and step == 1)))
+        for step in range(3):
+            # "rank": frozen on rank 1 only, from the first step; "later": on BOTH ranks, from step 1 (legal: torch.optim + DDP allow
+            # it); "later-one-rank": on rank 1 only, from step 1
+            off = (mode == "rank" and rank == 1) or (mode == "later" and step >= 1) or (mode == "later-one-rank" and rank == 1 and step >= 1)
+            frozen.requires_grad_(not off)
             model.train()
-            opt.zero_grad()
-            unet_amd.seg_loss(model(im), mk, 1, reduce_sums=unet_amd.dp.make_sum_reducer(None), world=world)["loss"].backward()
             try:
-                opt.step()
+                unet_amd.train_step(model, opt, im, mk, amp=False, reduce_sums=reduce_sums, world=world)
             except RuntimeError as e:
                 err = (step, str(e))
                 break
@@ -377,20 +378,23 @@ def _stale_pattern_worker(rank, world, port, q, mode):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["rank", "later"])
+@pytest.mark.parametrize("mode", ["rank", "later", "later-one-rank"])
 def test_a_parameter_stale_on_one_rank_only_is_refused(mode):
     """torch.optim behind DDP updates a parameter on every rank or on none (the all-reduce makes .grad non-None everywhere); the
     fused optimizer skips locally stale slices, so a parameter that is fresh on one rank and stale on another would diverge
-    silently.  The pattern is agreed on the first step (both ranks raise) and may not change later (a local test: no rank is left
-    waiting at a collective the others skip)."""
+    silently.  The pattern is agreed on the first step (both ranks raise before any update).  Later it may change on every rank
+    alike (freezing a layer mid-run); a change on one rank only is caught by the checksum that rides in the next step's NaN-flag
+    all-reduce -- a collective every rank issues every step -- and BOTH ranks raise together, one step late (no rank may
+    be left waiting at a collective its peer has abandoned)."""
     res = _spawn(_stale_pattern_worker, mode)
-    for rank, _, err in res:
-        assert err is not None, f"rank {rank} stepped although the ranks disagree"
-        step, msg = err
+    for rank, status, err in res:
+        assert status == "ok", (rank, status)
         if mode == "rank":
-            assert step == 0 and "some ranks" in msg, (rank, err)
+            assert err is not None and err[0] == 0 and "some ranks" in err[1], (rank, err)
+        elif mode == "later":
+            assert err is None, (rank, err)
         else:
-            assert step == 1 and "changed between steps" in msg, (rank, err)
+            assert err is not None and err[0] == 2 and "previous step" in err[1], (rank, err)
 
 
 # ------------------------------------------------------------------------------------------ the real backend, one rank

@@ -412,7 +412,9 @@ def test_full_unet_step_bf16_against_the_reference_graph_under_autocast():
     c = Collector("UNet 96x64")
     c.tensor("logits", terms["logits"].float(), ref[False]["logits"], ref[True]["logits"])
     for q in ("bce", "dice", "boundary", "loss", "grad_norm"):
-        c.scalar(q, float(terms[q].detach()), ref[False][q], ref[True][q])
+        # (boundary_loss counts thresholded pixels, 12 288 of them here: a handful within bf16 round-off of the threshold move it
+        # -- and the loss that carries a quarter of it -- by whole counts)
+        c.scalar(q, float(terms[q].detach()), ref[False][q], ref[True][q], floor=1e-2 if q in ("boundary", "loss") else None)
     for k, p in model.named_parameters():
         c.tensor("grad " + k, stepper.optimizer.grad_of(p), ref[False]["grads"][k], ref[True]["grads"][k])
     c.done()
@@ -596,7 +598,7 @@ def test_batched_slab_reduction_is_bit_identical_to_the_per_layer_launches(amp, 
                 t = st.step(im.to(dev), mk.to(dev))
             torch.cuda.synchronize()
             if defer:
-                assert st._slabs._table is not None and st._slabs._table[1] == 17 and not st._slabs.rows     # 17 MFMA layers queued, flushed
+                assert len(st._slabs._tables) == 1 and next(iter(st._slabs._tables.values()))[1] == 17 and not st._slabs.rows     # 17 MFMA layers queued, flushed
             res.append((float(t["loss"].detach()), st.optimizer.flat_p.clone(), st.optimizer.flat_g.clone()))
             st.close()
     finally:

@@ -57,9 +57,10 @@ class Collector:
         n = int(np.asarray(ref32.detach().cpu() if torch.is_tensor(ref32) else ref32).size)
         self.add(what, l2(hip, ref32), l2(ref16, ref32), floor, FACTOR_LOOSE if (loose or n < 1024) else FACTOR)
 
-    def scalar(self, what, hip, ref32, ref16, loose=False):
+    def scalar(self, what, hip, ref32, ref16, loose=False, floor=None):
         r = float(ref32)
-        self.add(what, abs(float(hip) - r) / abs(r), abs(float(ref16) - r) / abs(r), ULP, FACTOR_LOOSE if loose else FACTOR)
+        self.add(what, abs(float(hip) - r) / abs(r), abs(float(ref16) - r) / abs(r), ULP if floor is None else floor,
+                 FACTOR_LOOSE if loose else FACTOR)
 
     def done(self):
         dump()

@@ -538,6 +538,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_mfma(
 //     window of 3 rows); the filter fragments of the next column shift are prefetched under the current one;
 //   * BatchNorm (mean, M2) per tile and channel come straight from the accumulator registers + 4 shuffles.
 // =====================================================================================
+// Diagnostic builds (scratch/r5_mklib.py NAME -DUH_ABL_X=1, scratch/r5_ablate.sh): each switch removes ONE class of work from the
+// forward / backward-data kernel's tile loop -- results are garbage, launch times say what that work costs where it sits.
+//   UH_ABL_NOW     no filter-fragment loads inside the chunk loop       UH_ABL_NODMA   no halo DMA inside the loop
+//   UH_ABL_NOLDS   no pixel-fragment LDS reads (opaque stale registers) UH_ABL_NOMFMA  no MFMAs
+//   UH_ABL_NOSTORE no output stores                                     UH_ABL_NOSTATS no BatchNorm statistics
+#ifndef UH_ABL_NOW
+#define UH_ABL_NOW 0
+#endif
+#ifndef UH_ABL_NODMA
+#define UH_ABL_NODMA 0
+#endif
+#ifndef UH_ABL_NOLDS
+#define UH_ABL_NOLDS 0
+#endif
+#ifndef UH_ABL_NOMFMA
+#define UH_ABL_NOMFMA 0
+#endif
+#ifndef UH_ABL_NOSTORE
+#define UH_ABL_NOSTORE 0
+#endif
+#ifndef UH_ABL_NOSTATS
+#define UH_ABL_NOSTATS 0
+#endif
 constexpr int HALO2_BYTES = HALO_PIX * 64;   // 20736
 constexpr int HALO2_STRIDE = 6 * 4096;       // LDS bytes per halo buffer: six 4 KiB DMA rounds of 256 threads (the tail is padding)
 constexpr unsigned OOB_OFFSET = 0xF0000000u;
@@ -710,6 +733,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     int rel0[NLOAD];
 #pragma unroll
     for (int k = 0; k < NLOAD; ++k) rel0[k] = REL_LIVE ? rel_of(tid, k) : 0;
+    bool abl_first_dma = true; (void)abl_first_dma;
     // tile the NEXT DMA reads from (scalars): image, top-left pixel, "halo inside the image"
     int d_b = 0, d_y0 = 0, d_x0 = 0;
     bool d_in = false;
@@ -725,6 +749,9 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     // past the halo tile (and `live == false`: nothing left to fetch) read out of range, i.e. write zeros into the padding
     // of the buffer / into a buffer nobody reads.
     auto dma_chunk = [&](int c, int bufi, bool live) {
+#if UH_ABL_NODMA
+        if (!abl_first_dma) return;
+#endif
         const int cc = c * CK;
         const bool first = cc < C0;
         const int ld = first ? ld0 : ld1;
@@ -788,17 +815,17 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     //                                   so that the row order, and with it the fragment-major filter pack (uh_wfrag_index),
     //                                   depends on the dtype and Cout only, not on which instantiation a launch picks;
     //   fp32:                           the MFMA's own order wave*16*NBW + n*16 + grp*4 + j (16 bytes per lane already).
-    constexpr bool PERM2 = (ES == 2 && NBW == 2);
+    constexpr bool PERM2 = (ES == 2 && NBW >= 2);
     const bool half32 = (ES == 2 && NBW == 1) && (Cout % 128 == 0);
     const bool perm1 = (ES == 2 && NBW == 1) && !half32;
     auto ch = [&](int grp, int n, int j) -> int {       // grp = row >> 2 (= kg for accumulators), j = row & 3
-        if constexpr (PERM2) return wave * 32 + grp * 8 + n * 4 + j;
+        if constexpr (PERM2) return wave * (16 * NBW) + (n >> 1) * 32 + grp * 8 + (n & 1) * 4 + j;
         else if constexpr (ES == 2) return half32 ? ((wave >> 1) * 32 + grp * 8 + (wave & 1) * 4 + j)
                                                   : (wave * 16 + ((((grp & 1) << 1) | (grp >> 1)) << 2) + j);
         else return wave * (16 * NBW) + n * 16 + grp * 4 + j;
     };
     const int wrow0 = co_blk + ch(lx >> 2, 0, lx & 3);
-    const int64_t wnb_stride = (int64_t)(PERM2 ? 4 : 16) * 9 * Cin;
+    auto wn_off = [&](int n) -> int64_t { return (int64_t)(PERM2 ? ((n >> 1) * 32 + (n & 1) * 4) : n * 16) * 9 * Cin; };   // filter rows of MFMA n behind MFMA 0's (KRSC packs)
     // Filter fragments come through a buffer descriptor: ONE per-lane byte offset (the lane's filter row and 16-byte part)
     // plus a wave-uniform byte offset in an SGPR (chunk, tap, n) -- no 64-bit address arithmetic in vector registers -- as
     // asynchronous loads whose waits are placed by hand (uh_ld16_async).
@@ -811,7 +838,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     const int wg0 = (co_blk >> 4) + wave * NBW, nch_all = Cin / CK;
     struct WFrag { u32x4 v; u32x2 hi, lo; };     // non-SPLIT: v = the fragment; SPLIT: hi / lo = the bf16 halves of 4 values
     constexpr int NWLOAD = 3 * NBW * (SPLIT ? 2 : 1);      // load instructions per column shift (one weight set)
-    auto wfrag_async = [&](WFrag& dst, int64_t off, int n, int tap, int chunk) {    // off = n * wnb_stride + tap * Cin + chunk offset (elements)
+    auto wfrag_async = [&](WFrag& dst, int64_t off, int n, int tap, int chunk) {    // off = wn_off(n) + tap * Cin + chunk offset (elements)
         // ONE asm statement per destination: with a load in each arm of a branch the compiler merges the two "results"
         // with register copies behind the branch -- executed before the data has arrived (asynchronous destination)
         if constexpr (SPLIT) {
@@ -914,12 +941,16 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
             wA[r][n].v = wB[r][n].v = wC[r][n].v = u32x4{0u, 0u, 0u, 0u};
             wA[r][n].hi = wB[r][n].hi = wC[r][n].hi = wA[r][n].lo = wB[r][n].lo = wC[r][n].lo = u32x2{0u, 0u};
         }
+    bool abl_first = true; (void)abl_first;
     auto load_w = [&](WFrag (&dst)[3][NBW], int chunk, int sft) {      // the three row taps of column shift `sft`, chunk `chunk`
+#if UH_ABL_NOW
+        if (!abl_first) return;
+#endif
         const int64_t wsrc = (int64_t)chunk * CK + (int64_t)sft * Cin;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int n = 0; n < NBW; ++n) wfrag_async(dst[r][n], wsrc + n * wnb_stride + (int64_t)(r * 3) * Cin, n, r * 3 + sft, chunk);
+            for (int n = 0; n < NBW; ++n) wfrag_async(dst[r][n], wsrc + wn_off(n) + (int64_t)(r * 3) * Cin, n, r * 3 + sft, chunk);
     };
     int bufi = 0;
     // one column shift: rolling window over the 18 halo rows, row k+1 is fetched from LDS while output row k-2 is multiplied
@@ -930,7 +961,13 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
         int lq = lane;
         if constexpr (!REL_LIVE) asm volatile("" : "+v"(lq));       // (same register shortage: the three column offsets are not kept either)
         const unsigned char* xcol = buf + ((lq & 15) + sft) * 64 + (((lq >> 4) ^ halo_swz((lq & 15) + sft)) << 4);
+#if UH_ABL_NOLDS
+        u32x4 abl_x = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        asm volatile("" : "+v"(abl_x));
+        auto rd = [&](int k) { u32x4 v = abl_x; asm volatile("" : "+v"(v)); (void)xcol; return v; };
+#else
         auto rd = [&](int k) { return *reinterpret_cast<const u32x4*>(xcol + k * (HALO_W * 64)); };
+#endif
 #pragma unroll
         for (int k = 0; k < 2 + PF; ++k) xf[k] = rd(k);
 #pragma unroll
@@ -947,8 +984,12 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     if constexpr (ES == 2) {
+#if UH_ABL_NOMFMA
+                        asm volatile("" : "+v"(acc[i][n]) : "v"(xf[i + r]), "v"(wget(r, n).v));
+#else
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, wget(r, n).v), __builtin_bit_cast(bf16x8, xf[i + r]), acc[i][n], 0, 0, 0);
+#endif
                     } else if constexpr (SPLIT) {
                         const s16x4 wh = __builtin_bit_cast(s16x4, wget(r, n).hi);
                         const s16x4 wlo = __builtin_bit_cast(s16x4, wget(r, n).lo);
@@ -985,7 +1026,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     wres[c][t][n].v = u32x4{0u, 0u, 0u, 0u};
-                    wfrag_async(wres[c][t][n], (int64_t)c * CK + n * wnb_stride + (int64_t)t * Cin, n, t, c);
+                    wfrag_async(wres[c][t][n], (int64_t)c * CK + wn_off(n) + (int64_t)t * Cin, n, t, c);
                 }
         if constexpr (TRI) dma_chunk(1, 1, true);      // (behind the filter: the first fence leaves exactly these six in flight)
     } else {
@@ -1005,6 +1046,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
         __builtin_amdgcn_sched_barrier(0);
     }
     chunk_fence(chunk_of(v_first), 0, true);
+    abl_first = false; abl_first_dma = false;
 
     for (; tile < ntile; tile += nlanes) {
         if (KS == 2 && tile != tile_lane) break;     // (one tile per workgroup: the host sizes the grid that way)
@@ -1279,11 +1321,13 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
         // offset is ADDED to the vector offset instead of riding in the scalar-offset operand: a 16-byte buffer store with a
         // scalar offset register reads its data over several cycles, and hipcc (ROCm 7.2) let the next VALU instruction
         // overwrite the first data register behind the last store of the loop (wrong bf16 pairs in 8 lanes of one row pair).
-        {
+        if (!UH_ABL_NOSTORE) {
             const int rbytes = W * ldy * ES;                                   // one image row of y
             const int sbase = ((b * H + y0) * W) * ldy * ES;                   // row 0 of the tile, column 0
             if constexpr (PERM2) {
-                const int c0 = co_blk + ch(kg, 0, 0);
+#pragma unroll
+                for (int hp = 0; hp < NBW / 2; ++hp) {             // one 16-byte piece (8 channels) per pair of MFMAs
+                const int c0 = co_blk + ch(kg, 2 * hp, 0);
                 const bool inr = gx < W && c0 < Coutv;
                 const unsigned voff = (unsigned)((gx * ldy + c0) * ES);
                 if (full) {
@@ -1293,8 +1337,8 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
                     unsigned vo = inr ? voff + (unsigned)sbase : OOB_OFFSET;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
-                                    (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
+                        bf16x8 o = {(bf16_t)acc[i][2 * hp][0], (bf16_t)acc[i][2 * hp][1], (bf16_t)acc[i][2 * hp][2], (bf16_t)acc[i][2 * hp][3],
+                                    (bf16_t)acc[i][2 * hp + 1][0], (bf16_t)acc[i][2 * hp + 1][1], (bf16_t)acc[i][2 * hp + 1][2], (bf16_t)acc[i][2 * hp + 1][3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, vo, 0, 0);
                         vo += (unsigned)rbytes;
                     }
@@ -1302,10 +1346,11 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (i < vy) {
-                        bf16x8 o = {(bf16_t)acc[i][0][0], (bf16_t)acc[i][0][1], (bf16_t)acc[i][0][2], (bf16_t)acc[i][0][3],
-                                    (bf16_t)acc[i][1][0], (bf16_t)acc[i][1][1], (bf16_t)acc[i][1][2], (bf16_t)acc[i][1][3]};
+                        bf16x8 o = {(bf16_t)acc[i][2 * hp][0], (bf16_t)acc[i][2 * hp][1], (bf16_t)acc[i][2 * hp][2], (bf16_t)acc[i][2 * hp][3],
+                                    (bf16_t)acc[i][2 * hp + 1][0], (bf16_t)acc[i][2 * hp + 1][1], (bf16_t)acc[i][2 * hp + 1][2], (bf16_t)acc[i][2 * hp + 1][3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, inr ? voff + (unsigned)(sbase + i * rbytes) : OOB_OFFSET, 0, 0);
                     }
+                }
                 }
                 }
             } else if (perm1) {
@@ -1355,7 +1400,7 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
 
         // ---- BatchNorm statistics: pivot-shifted sums per lane, 4 DPP adds per channel, accumulated in LDS by the lane that
         // owns the channel's slot (the same lane every tile: no barrier, a wave only touches its own channels)
-        if (!BSUM && stats) {
+        if (!BSUM && stats && !UH_ABL_NOSTATS) {
             float* S1 = &wg_sum[0][0];          // slot = channel - co_blk: a wave touches its own channels only
             float* S2 = &wg_sum[1][0];
             float* PV = &wg_sum[2][0];
@@ -2642,9 +2687,13 @@ __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __rest
     auto add = [](f32x4& l, f32x4& h, const u32x4 v, const float sc) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f16x2 p = __builtin_bit_cast(f16x2, v[e]);
-            l[e] = fmaf((float)p[0], sc, l[e]);            // (a power of two: the product is exact, the fma rounds the sum once)
-            h[e] = fmaf((float)p[1], sc, h[e]);
+            // (the two halves through 16-bit scalars: with __builtin_bit_cast(f16x2, v[e]) hipcc 7.2 loaded ONE dword of the piece and
+            // fed the other three lanes of the packed fma from registers nobody had written)
+            const unsigned w = v[e];
+            const float a = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+            const float b = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+            l[e] = fmaf(a, sc, l[e]);                       // (a power of two: the product is exact, the fma rounds the sum once)
+            h[e] = fmaf(b, sc, h[e]);
         }
     };
     const int64_t e0 = (i4 < n4 ? i4 : 0) << 2;           // first dword of the piece

@@ -84,7 +84,8 @@ class FusedRMSprop:
         self._closed = False
         # one backward per step: which slices of flat_g hold THIS step's gradient (reset by zero_grad / step)
         self._fresh = [False] * len(self.params)
-        self._stale_verified = None                  # data parallel: the fresh / stale pattern the ranks agreed on (first step)
+        self._stale_verified = None                  # data parallel: the fresh / stale pattern of the last step (agreed on the first)
+        self._probe, self._probe_code = None, None
         with torch.no_grad():
             for i, (p, (o, n)) in enumerate(zip(self.params, slices)):
                 if p.dtype != torch.float32:
@@ -177,12 +178,31 @@ class FusedRMSprop:
             self.sync.wait()
         self._fresh = [False] * len(self.params)
 
+    @staticmethod
+    def _pattern_code(pattern) -> float:
+        """A small integer (exact in fp32, its square times the world size too) that names a fresh / stale pattern."""
+        return float(1 + sum((i + 1) * 7919 for i, f in enumerate(pattern) if f) % 4093)
+
+    def pattern_probe(self) -> Optional[torch.Tensor]:
+        """Data parallel: [c, c^2] of the pattern the LAST step ran with (device tensor, rewritten only when the pattern changes).
+        train_step appends it to the NaN-flag all-reduce every rank issues every step anyway: sum(c^2) * world == sum(c)^2 iff
+        every rank had the same pattern."""
+        if self.sync is None or self._stale_verified is None:
+            return None
+        code = self._pattern_code(self._stale_verified)
+        if self._probe is None or self._probe_code != code:
+            self._probe = torch.tensor([code, code * code], dtype=torch.float32, device=self.flat_g.device)
+            self._probe_code = code
+        return self._probe
+
     def _check_stale_pattern(self):
         """Data parallel: "skip a parameter that got no gradient" is only what torch.optim + DDP do when EVERY rank skips it
         (behind DDP's all-reduce .grad is non-None on every rank).  A parameter that is fresh on one rank and stale on another
         would be updated on one replica only, silently.  The pattern is therefore compared across the ranks on the first
-        step (one tiny all-reduce + host read, once), and must not change afterwards (a purely local test, so no rank can
-        be left waiting at a collective the others skip).  U-Net uses every parameter on every step: this never fires there."""
+        step (one tiny all-reduce + host read, once).  Afterwards it MAY change -- freezing or unfreezing layers mid-run is
+        legal with torch.optim + DDP -- as long as it changes on every rank alike: each step's pattern rides, as a checksum, in
+        the NEXT step's NaN-flag all-reduce (pattern_probe; a collective every rank issues every step, so nobody can be left
+        waiting), and a mismatch raises on all ranks together, one step late.  U-Net uses every parameter on every step."""
         pattern = tuple(self._fresh)
         if self._stale_verified is None:
             import torch.distributed as dist
@@ -190,14 +210,21 @@ class FusedRMSprop:
             both = torch.stack([bits, -bits])
             dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.sync.group)     # max(bits), -min(bits)
             if bool((both[0] != -both[1]).any().item()):
+                # (every rank takes this branch: the buckets are drained and the step is abandoned before anyone raises)
+                self.sync.wait()
+                self._fresh = [False] * len(self.params)
                 raise RuntimeError("FusedRMSprop (data parallel): a parameter received a gradient on some ranks and none on "
                                    "others; the replicas would diverge (give every rank the same set of trainable / used "
                                    "parameters)")
-            self._stale_verified = pattern
-        elif pattern != self._stale_verified:
-            raise RuntimeError("FusedRMSprop (data parallel): the set of parameters that receive gradients changed between "
-                               "steps; it was agreed across the ranks on the first step and cannot be re-checked without a "
-                               "blocking collective")
+        self._stale_verified = pattern
+
+    def check_probe(self, s1: float, s2: float, world: int):
+        """Host side of pattern_probe: s1 = sum of the ranks' codes, s2 = sum of their squares (read with the NaN flag)."""
+        if abs(s2 * world - s1 * s1) > 0.5:
+            self.abort_step()
+            raise RuntimeError("FusedRMSprop (data parallel): in the previous step the set of parameters that received gradients "
+                               "differed between the ranks; the replicas have diverged by one update (give every rank the same "
+                               "set of trainable / used parameters)")
 
     @torch.no_grad()
     def step(self):
@@ -299,12 +326,13 @@ def _one_like(loss: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _pinned_flag(device) -> torch.Tensor:
-    """A pinned float the NaN flag is copied into (one per device: it is read back before the next step writes it)."""
+def _pinned_flag(device, n: int = 1) -> torch.Tensor:
+    """Pinned floats the NaN flag (and, data parallel, the pattern probe) are copied into (one buffer per device: it is read
+    back before the next step writes it)."""
     t = _PINNED.get(device)
     if t is None:
-        t = _PINNED[device] = torch.zeros(1, dtype=torch.float32).pin_memory()
-    return t
+        t = _PINNED[device] = torch.zeros(4, dtype=torch.float32).pin_memory()
+    return t[:n]
 
 
 def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: torch.Tensor, *, amp: bool = True,
@@ -340,11 +368,16 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
         flag = nan_flag
         if flag is None or cc_loss:
             flag = torch.isnan(loss.detach()).reshape(1).float()
+        probe = None
         if reduce_sums is not None:
             # data parallel: boundary_loss (and so the loss value) is per rank; every rank must take the SAME decision, or
-            # the ranks that continue hang at their next collective while one has raised
+            # the ranks that continue hang at their next collective while one has raised.  The same all-reduce carries the
+            # checksum of the previous step's fresh / stale gradient pattern (FusedRMSprop.pattern_probe).
+            probe = optimizer.pattern_probe() if isinstance(optimizer, FusedRMSprop) else None
+            if probe is not None:
+                flag = torch.cat([flag.reshape(1), probe])
             flag = reduce_sums(flag)
-        nan_host = _pinned_flag(loss.device)
+        nan_host = _pinned_flag(loss.device, flag.numel())
         nan_host.copy_(flag, non_blocking=True)
         nan_event = torch.cuda.Event()
         nan_event.record()
@@ -354,7 +387,10 @@ def train_step(model: nn.Module, optimizer, images: torch.Tensor, true_masks: to
     ops.flush_slabs()            # the backward-weights reductions that waited for one batched launch (ops.SlabBatch)
     if nan_event is not None:
         nan_event.synchronize()
-        if float(nan_host.item()) > 0:
+        host = nan_host.tolist()
+        if len(host) == 3:
+            optimizer.check_probe(host[1], host[2], optimizer.sync.world)     # (`world` may be a ragged shard's gb / lb: the group's size counts)
+        if host[0] > 0:
             if isinstance(optimizer, FusedRMSprop):
                 optimizer.abort_step()
             raise RuntimeError("Fatal: NaN loss detected!")                                   # train.py:149-151
@@ -455,6 +491,12 @@ class TrainStepper:
         """The stream backward-weights runs on in the step over `images` (None: the launch stream)."""
         if self.wgrad_stream is None or not self._side_auto:
             return self.wgrad_stream
+        if self.sync_bn is not None and self.bn_group is None:
+            # SyncBN's collectives share the gradient communicator (one RCCL stream): a BatchNorm-backward all_reduce on the critical
+            # path would queue behind bucket all-reduces that wait for side-stream events.  Unmeasured over RCCL with more than
+            # one rank (one-GPU boxes), so the automatic choice stays on the safe side: one stream.  UH_SYNCBN_OWN_GROUP=1 (a
+            # communicator of its own) or an explicit wgrad_stream=True keep the side stream.
+            return None
         big = images.is_cuda and images.shape[0] * images.shape[-2] * images.shape[-1] >= self.SIDE_MIN_PIXELS
         return self.wgrad_stream if (self.amp and big) else None
 
