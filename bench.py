@@ -34,7 +34,7 @@ FWD_GFLOP_PER_IMAGE = {True: 319.237, False: 384.735}      # keyed by `bilinear`
 TRAIN_GFLOP_PER_IMAGE = {True: 957.41, False: 1153.90}     # fwd + dgrad + wgrad - dgrad(stem)
 MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
-TRAFFIC_PROFILE = "r04_hbm_traffic_pmc.json"               # HBM bytes per launch from the PMC passes (profiles/README.md)
+TRAFFIC_PROFILE = "r05_hbm_traffic_pmc.json"               # HBM bytes per launch from the PMC passes (profiles/README.md)
 
 
 def source_sha256(name: str) -> str:

@@ -47,7 +47,7 @@ def main():
                 fused.add(l[0])
     avg = {k: sum(v) / len(v) for k, v in t.items()}
     lines = ["# 3x3 conv launches of one train step, layer by layer", "", note, "",
-             "Backward-weights time is the MFMA kernel alone (its `slab_reduce` launch, ~10 us since the slabs are bf16 pairs, is not included). TFLOP/s = 2*B*H*W*Cout*9*Cin / time. "
+             "Backward-weights time is the MFMA kernel alone (its `slab_reduce` launch, ~10 us: the slabs are 16-bit pairs, is not included). TFLOP/s = 2*B*H*W*Cout*9*Cin / time. "
              "`*` = backward-data launches that also form the BatchNorm-backward sums of the layer in front (`uh_conv3x3_dgrad_bnsum`): their time includes "
              "what `uh_bn_relu_bwd_reduce` used to spend in a launch of its own.", "",
              "| layer | H=W | Cin | Cout | GFLOP | forward us | TFLOP/s | backward-data us | TFLOP/s | backward-weights us | TFLOP/s |", "|---|---|---|---|---|---|---|---|---|---|---|"]

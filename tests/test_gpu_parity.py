@@ -627,3 +627,5 @@ def test_full_unet_step_fp32_bf16x3_vs_oracle():
     check(t["logits"], ref["logits"], 2e-4, "bf16x3 logits")
     check(t["loss"], ref["loss"], 1e-4, "bf16x3 loss")
     check(t["grad_norm"], ref["grad_norm"], 3e-2, "bf16x3 grad norm")
+    from unet_amd import ops
+    assert ops.FP32_MODE == "exact", "a stepper's fp32 mode is a per-step setting: it must not leak into later calls of the process"

@@ -515,7 +515,8 @@ class TrainStepper:
             gb = int(global_batch) if global_batch is not None else dpmod.global_batch(lb, self.group, images.device)
             ops.SYNC_BN_BATCH = (gb, lb)
             world = gb / lb               # ragged shards: the loss is normalised by the GLOBAL pixel count n * gb / lb
-        ops.FP32_MODE = self.fp32_mode
+        fp32_mode_before, ops.FP32_MODE = ops.FP32_MODE, self.fp32_mode        # (a per-step setting: restored below, so that one
+        # stepper's bf16x3 products do not leak into whatever runs next in the process)
         # one launch packs every 3x3 filter (bf16/fp32 KRSC + backward-data layout) for this step's forward/backward
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
@@ -531,6 +532,7 @@ class TrainStepper:
                               reduce_sums=self.reduce_sums, world=world, check_nan=self.check_nan, cc_loss=self.cc_loss)
         finally:
             ops.SLAB_BATCH = None
+            ops.FP32_MODE = fp32_mode_before
 
 
 class GraphedTrainStepper(TrainStepper):
@@ -555,7 +557,7 @@ class GraphedTrainStepper(TrainStepper):
         side = self._side_for(images)
         ops.WGRAD_STREAM = side
         ops.SYNC_BN = None
-        ops.FP32_MODE = self.fp32_mode
+        fp32_mode_before, ops.FP32_MODE = ops.FP32_MODE, self.fp32_mode
         dt = torch.bfloat16 if self.amp else getattr(self.model, "compute_dtype", torch.float32)
         if self._pack is None or self._pack.dtype != dt:
             ws = [m.weight for m in self.model.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)]
@@ -570,6 +572,7 @@ class GraphedTrainStepper(TrainStepper):
                               world=self.world, check_nan=False)
         finally:
             ops.SLAB_BATCH = None
+            ops.FP32_MODE = fp32_mode_before
 
     def _capture(self, images, masks):
         opt = self.optimizer
