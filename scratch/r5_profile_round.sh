@@ -5,7 +5,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --no-inference --no-sustained --no-b4-leg --no-side-stream"      # (one stream: every kernel alone, durations comparable with the live events of bench.py)
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --no-inference --no-sustained --no-b4-leg --no-strong-leg --no-side-stream"      # (one stream: every kernel alone, durations comparable with the live events of bench.py)
 exp() { db=$(find $1 -name "*.db" | head -1); python3 $R/scratch/rocpd_export.py $2 $db $3; rm -rf $1; }
 for b in 8 4; do
   rocprofv3 --kernel-trace --stats -d $OUT/st$b -- $BENCH --batch $b --steps 10 --warmup 3 > $OUT/stats_b$b.log 2>&1 || { echo "stats pass failed"; tail -5 $OUT/stats_b$b.log; exit 1; }

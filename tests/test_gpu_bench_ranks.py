@@ -30,7 +30,11 @@ COMMON = ["--steps", "2", "--warmup", "1", "--size", "128", "--no-cpu-baseline",
 
 def test_one_rank_line_is_unchanged():
     out = _bench(["--gpus", "1"] + COMMON)
-    assert out["n_gpus"] == 1 and "collective" not in out and "strong_gb32" not in out
+    assert out["n_gpus"] == 1 and "collective" not in out
+    # (round 5: the fixed-global-batch leg runs at N = 1 too -- 32 images on the one GPU -- so that 1 -> N scaling at global batch 32
+    # is the ratio of two strong_gb32 figures measured the same way)
+    sg = out["strong_gb32"]
+    assert sg["global_batch"] == 32 and sg["per_gpu_batch"] == 32 and sg["images_per_sec"] > 0 and sg["exposed_allreduce_ms_per_step"] is None
     assert out["scaling"] == "weak" and out["sustained"]["steps"] >= 2
     assert out["roofline"]["bound"] == "mfma" and "double_conv_256_after_sustained" in out["kernels"]
     # every launch of the forward / backward-data kernel beside the plain family, and config 3's per-GPU batch on one GPU

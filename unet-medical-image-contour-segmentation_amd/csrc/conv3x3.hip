@@ -627,6 +627,8 @@ constexpr int PRE_MAX_C = 512;
 template <typename T, int NBW, bool SPLIT = false, bool WRES = false, bool PRE = false, bool BSUM = false, int KS = 1>
 // (three workgroups per CU -- 168 registers -- for the 16-channel-per-wave form; its BSUM instantiation needs more than that for
 // the epilogue's batches and spilled 42 instructions per tile at 168: two per CU, like the other wide-register forms)
+// (round 5: the register-resident-filter form does not fit three per CU either -- at 168 registers hipcc 7.2 spills 36 instructions into its
+// MFMA stream and parks in-flight filter destinations in scratch; the ISA lint refuses the build)
 __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) ? 3 : 2)) void conv3x3_fwd_mfma_v2(
     const T* __restrict__ x0, int C0, int ld0, const T* __restrict__ x1, int C1, int ld1,
     const T* __restrict__ w, T* __restrict__ y, int ldy, int Cout, float* __restrict__ stats,
