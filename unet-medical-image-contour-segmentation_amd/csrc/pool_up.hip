@@ -277,134 +277,6 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const T* __res
     }
 }
 
-// Round 5: the same arithmetic with every input piece loaded -- and, in the PRE form, normalised, clipped and rounded -- ONCE per
-// workgroup instead of once per output column that reads it.  A thread of the kernel above loads two columns x four rows for its
-// four output rows, although neighbouring output columns read the same two input columns: at scale ~1/2 every input piece was
-// fetched, unpacked and (PRE) pushed through fma / max / round by two threads per row group -- and the kernel is VALU-bound.  Here
-// the workgroup's input window (NR rows x the columns its output columns touch x every channel group) is staged through LDS in the
-// tensor's own type: the PRE result is rounded to T by definition, so what a consumer reads back is bit for bit what it would have
-// computed itself, and the two interpolation stages are the kernel's above, operand for operand.  Bit-identical outputs.
-// LDS: NR x ncols x G 16-byte pieces with ncols <= 128 / G + 3 (a workgroup spans 256 / G output columns): <= 32 KB for G <= 128.
-constexpr int UP_LDS_PIECES = 2048;
-template <typename T, int V, bool PRE = false>
-__global__ __launch_bounds__(256) void upsample2x_fwd_lds_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
-                                                                 int h, int w, int C, int Ho, int Wo, int pt, int pl,
-                                                                 float sy, float sx, int gshift,
-                                                                 const float* __restrict__ pre_scale = nullptr,
-                                                                 const float* __restrict__ pre_shift = nullptr) {
-    constexpr int R = UP_ROWS;
-    constexpr int NR = R / 2 + 2;
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    __shared__ u32x4_t stage[UP_LDS_PIECES];
-    const int G = C / V;
-    const int groups = (Ho + R - 1) / R;
-    const int b = blockIdx.x / groups, oy0 = (blockIdx.x - b * groups) * R;
-    const int t = blockIdx.y * 256 + threadIdx.x;
-    const bool live = t < Wo * G;
-    const int ox = gshift >= 0 ? (t >> gshift) : (t / G);
-    const int c = (t - ox * G) * V;
-    const int ux = ox - pl;
-    const bool col_in = live && ux >= 0 && ux < 2 * w;
-    // vertical coordinates of the R output rows (scalar), as in the kernel above
-    UpCoord cy[R];
-    bool row_in[R];
-    int base = h - 1;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int uy = oy0 + r - pt;
-        row_in[r] = (oy0 + r < Ho) && uy >= 0 && uy < 2 * h;
-        cy[r] = up_coord(row_in[r] ? uy : 0, sy, h);
-        if (row_in[r] && cy[r].i0 < base) base = cy[r].i0;
-    }
-    // the workgroup's output columns (uniform) and the input columns they touch
-    const int t_lo = blockIdx.y * 256, t_hi = min(t_lo + 255, Wo * G - 1);
-    const int ox_lo = gshift >= 0 ? (t_lo >> gshift) : (t_lo / G), ox_hi = gshift >= 0 ? (t_hi >> gshift) : (t_hi / G);
-    const int ux_lo = max(ox_lo - pl, 0), ux_hi = min(ox_hi - pl, 2 * w - 1);
-    int ix_lo = 0, ncols = 0;
-    if (ux_lo <= ux_hi) {
-        ix_lo = up_coord(ux_lo, sx, w).i0;
-        ncols = up_coord(ux_hi, sx, w).i1 - ix_lo + 1;
-    }
-    const int per_row = ncols * G, npiece = NR * per_row;
-    if (npiece > UP_LDS_PIECES) return;                              // (never: up_lds_ok bounds ncols <= (span - 1) / 2 + 3; uniform, so no barrier is skipped by a part of the workgroup)
-    float sc[PRE ? V : 1], sh[PRE ? V : 1];
-    int gcur = -1;                                                   // (G a power of two <= 256: a thread's channel group never changes, one coefficient load)
-    for (int p = threadIdx.x; p < npiece; p += 256) {
-        const int j = p / per_row, q = p - j * per_row;
-        const int ci = gshift >= 0 ? (q >> gshift) : (q / G), gi = q - ci * G;
-        const int iy = min(base + j, h - 1);
-        const T* src = x + ((int64_t)(b * h + iy) * w + ix_lo + ci) * ldx + gi * V;
-        if constexpr (PRE) {
-            if (gi != gcur) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) { sc[i] = pre_scale[gi * V + i]; sh[i] = pre_shift[gi * V + i]; }
-                gcur = gi;
-            }
-            float v[V];
-            uh_load<T, V>(src, v);
-#pragma unroll
-            for (int i = 0; i < V; ++i) v[i] = uh_round_as<T>(uh_relu(fmaf(v[i], sc[i], sh[i])));
-            uh_store<T, V>(reinterpret_cast<T*>(&stage[p]), v);
-        } else {
-            stage[p] = *reinterpret_cast<const u32x4_t*>(src);
-        }
-    }
-    __syncthreads();
-    if (!live) return;
-    float hr[NR][V];
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-#pragma unroll
-        for (int i = 0; i < V; ++i) hr[j][i] = 0.f;
-    if (col_in) {
-        const UpCoord cx = up_coord(ux, sx, w);
-        const int g0 = c / V;
-        const int s0 = (cx.i0 - ix_lo) * G + g0, s1 = (cx.i1 - ix_lo) * G + g0;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            float v0[V], v1[V];
-            uh_load<T, V>(reinterpret_cast<const T*>(&stage[j * per_row + s0]), v0);
-            uh_load<T, V>(reinterpret_cast<const T*>(&stage[j * per_row + s1]), v1);
-#pragma unroll
-            for (int i = 0; i < V; ++i) hr[j][i] = fmaf(cx.l0, v0[i], __fmul_rn(cx.l1, v1[i]));
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (oy0 + r >= Ho) break;
-        float o[V];
-#pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = 0.f;
-        if (row_in[r]) {
-            const int a = min(cy[r].i0 - base, NR - 1), bb = min(cy[r].i1 - base, NR - 1);
-            const float l0 = cy[r].l0, l1 = cy[r].l1;
-            auto blend = [&](const float (&ra)[V], const float (&rb)[V]) {
-                _Pragma("unroll") for (int i = 0; i < V; ++i) o[i] = fmaf(l0, ra[i], __fmul_rn(l1, rb[i]));
-            };
-            bool done = false;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                if (!done && a == j) {
-                    if (bb == j || j == NR - 1) blend(hr[j], hr[j]);
-                    else blend(hr[j], hr[j + 1 < NR ? j + 1 : j]);
-                    done = true;
-                }
-            }
-        }
-        uh_store<T, V>(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c, o);
-    }
-}
-// can the LDS-staged form take this shape?  NR * (columns a workgroup touches) * G pieces must fit the stage
-static inline bool up_lds_ok(int G) {
-    const int span = (255 + G - 1) / G + 1;                     // output columns a workgroup of 256 threads can straddle
-    const int ncols = span / 2 + 3;                             // i1(last) - i0(first) + 1 <= floor(scale * (span - 1)) + 3 with scale < 1 / 2
-    return (UP_ROWS / 2 + 2) * ncols * G <= UP_LDS_PIECES;
-}
-static inline bool up_lds_on() {
-    static const bool off = getenv("UH_UP_FWD_ROWS") != nullptr && getenv("UH_UP_FWD_ROWS")[0] == '1';      // A/B: the round-4 kernel
-    return !off;
-}
-
 // gather form of the transpose: every input pixel collects from the output pixels that read it
 __device__ __forceinline__ void up_range(int i, float scale, int in, int& lo, int& hi) {
     const int out = 2 * in;
@@ -629,10 +501,6 @@ extern "C" int uh_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int B
             for (int k = 0; k < 24; ++k)
                 if ((1 << k) == G) gshift = k;
             const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
-            if (up_lds_ok(G) && up_lds_on())
-                hipLaunchKernelGGL((upsample2x_fwd_lds_kernel<T, VEC>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
-                                   ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift);
-            else
             hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
                                ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift);
         } else if (uh_vec_ok<T>(x, ldx, C) && uh_vec_ok<T>(y, ldy, C))
@@ -671,10 +539,6 @@ extern "C" int uh_bn_relu_upsample2x_fwd(const void* x, int ldx, const float* sc
         for (int k = 0; k < 24; ++k)
             if ((1 << k) == G) gshift = k;
         const unsigned gy = (unsigned)(((int64_t)Wo * G + 255) / 256);
-        if (up_lds_ok(G) && up_lds_on())
-            hipLaunchKernelGGL((upsample2x_fwd_lds_kernel<T, VEC, true>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
-                               ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift, scale, shift);
-        else
         hipLaunchKernelGGL((upsample2x_fwd_rows_kernel<T, VEC, true>), dim3((unsigned)(B * ((Ho + UP_ROWS - 1) / UP_ROWS)), gy), dim3(256), 0, st, (const T*)x,
                            ldx, (T*)y, ldy, h, w, C, Ho, Wo, pad_top, pad_left, sy, sx, gshift, scale, shift);
     });
