@@ -53,6 +53,23 @@ def test_bf16x3_roofline_is_quoted_on_the_pipe_that_runs_it():
     assert abs(r["pipe_tflops"] - 3 * r["achieved"]) < 0.5, r
 
 
+def test_four_ranks_over_gloo_on_one_gpu_share_the_config_keys_of_the_one_rank_line():
+    """Round 5 (review item 8): the N-rank line and the one-rank line must carry the same `config` keys and the same
+    `strong_gb32` keys (the 1 -> N scaling at global batch 32 is the ratio of the two strong_gb32 figures); four ranks is what the
+    box's process limit allows on one card (the driver's run is eight, one per GPU, over RCCL)."""
+    one = _bench(["--gpus", "1"] + COMMON)
+    four = _bench(["--gpus", "4", "--backend", "gloo", "--share-gpu"] + COMMON)
+    assert four["n_gpus"] == 4 and four["collective"]["world"] == 4 and four["config"]["global_batch"] == 32
+    assert set(one["config"]) == set(four["config"])
+    assert four["strong_gb32"]["per_gpu_batch"] == 8 and one["strong_gb32"]["per_gpu_batch"] == 32
+    assert set(one["strong_gb32"]) == set(four["strong_gb32"])
+    col = four["collective"]
+    for key in ("backend", "world", "rccl_version", "per_gpu_batch", "global_batch", "grad_bytes", "grad_buckets", "bucket_bytes",
+                "allreduce", "sync_bn", "exposed_allreduce_ms_per_step"):
+        assert key in col, key
+    assert sum(col["bucket_bytes"]) == col["grad_bytes"] and len(col["bucket_bytes"]) == col["grad_buckets"]
+
+
 def test_two_ranks_over_gloo_on_one_gpu():
     out = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + COMMON)
     assert out["n_gpus"] == 2 and out["collective"]["world"] == 2 and out["collective"]["backend"] == "gloo"
