@@ -27,7 +27,7 @@ def load(d):
         e["dur"] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
     return list(rows.values())
 out = ["# rocprofv3 --pmc passes over scratch/r5_pmc_probe.py (4 forward conv shapes of config 2, batch 8, bf16; last 3 of 4 launches averaged):",
-       "# `base` = the shipped library, `NOW` = the diagnostic build without filter-fragment loads in the chunk loop (scratch/libs/libunet_hip_abl_NOW.so, results garbage by design).",
+       "# base = the shipped library, NOW = the diagnostic build without filter-fragment loads in the chunk loop (scratch/libs/libunet_hip_abl_NOW.so, results garbage by design).",
        "# mfma_ghz_equiv = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / duration (utilisation x clock); wait_inst = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; vmem_rd = SQ_INSTS_VMEM_RD per launch;",
        "# ta_busy = TA_BUSY_avr / (GRBM-free estimate: duration x 2.0 GHz) is NOT normalised here: the raw average busy cycles per TA are listed; tcc_hit = TCC_HIT / (HIT + MISS).",
        "layer,lib,dur_us,mfma_ghz_equiv,wait_inst_frac,wait_any_frac,vmem_rd_insts,ta_busy_avr_cycles,tcp_tcc_read_req,tcp_pending_stall_cycles,tcc_hit_rate"]

@@ -2681,7 +2681,7 @@ __global__ __launch_bounds__(256) void slab_reduce_tall_kernel(const float* __re
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
                                                           int64_t npair, int row, int nsplit, int coblk, int64_t blk,
-                                                          f32x4 (*red)[64]) {
+                                                          f32x4 (*red)[64], float* sc_tab) {
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i4 = blk * 64 + cl;
     const int64_t n4 = npair >> 2;
@@ -2698,23 +2698,40 @@ __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __rest
             h[e] = fmaf(b, sc, h[e]);
         }
     };
+    const int Cin = row / 9, nci = Cin >> 6;
+    const int nby = nci * (int)((npair * 2 / row) / coblk);
+    const float* scales_all = reinterpret_cast<const float*>(slabs + (int64_t)nsplit * npair);
+    // The inverse scales of the workgroup's output-channel block -- [nsplit][nci] floats, at most 512 -- are staged in LDS once: read
+    // one by one from memory they doubled the kernel's load instructions (15 us per launch against the bf16 form's 9.8).  A
+    // workgroup's 256 dwords lie in one or two row pairs; a piece whose row pair belongs to the NEXT block takes the memory path.
+    const int64_t cp_first = ((blk * 64) << 2) / row;
+    const int cot0 = (int)(2 * cp_first) / coblk;
+    const bool staged = nsplit * nci <= 512;
+    if (staged) {
+        for (int i = threadIdx.x; i < nsplit * nci; i += 256) {
+            const int k = i / nci, c = i - k * nci;
+            sc_tab[i] = scales_all[(int64_t)k * nby + cot0 * nci + c];
+        }
+    }
+    __syncthreads();
     const int64_t e0 = (i4 < n4 ? i4 : 0) << 2;           // first dword of the piece
     const int64_t cp = e0 / row, rem = e0 - cp * row;
     if (i4 < n4) {
-        const int Cin = row / 9, nci = Cin >> 6;
         const int tap = (int)(rem / Cin), ci = (int)(rem - (int64_t)tap * Cin);
-        const int nby = nci * (int)((npair * 2 / row) / coblk);
-        const float* scales = reinterpret_cast<const float*>(slabs + (int64_t)nsplit * npair) + ((int)(2 * cp) / coblk) * nci + (ci >> 6);
+        const int cot = (int)(2 * cp) / coblk, cit = ci >> 6;
+        const bool from_lds = staged && cot == cot0;
+        const float* scales = scales_all + cot * nci + cit;
+        const float* tab = sc_tab + cit;
+        auto scale_of = [&](int k) -> float { return from_lds ? tab[k * nci] : scales[(int64_t)k * nby]; };
         const u32x4* base = reinterpret_cast<const u32x4*>(slabs) + i4;
         int k = sl;
         for (; k + 12 < nsplit; k += 16) {           // four independent loads in flight per lane, added in a fixed order
             const u32x4 v0 = base[(int64_t)k * n4], v1 = base[(int64_t)(k + 4) * n4];
             const u32x4 v2 = base[(int64_t)(k + 8) * n4], v3 = base[(int64_t)(k + 12) * n4];
-            const float s0 = scales[(int64_t)k * nby], s1 = scales[(int64_t)(k + 4) * nby];
-            const float s2 = scales[(int64_t)(k + 8) * nby], s3 = scales[(int64_t)(k + 12) * nby];
+            const float s0 = scale_of(k), s1 = scale_of(k + 4), s2 = scale_of(k + 8), s3 = scale_of(k + 12);
             add(lo, hi, v0, s0); add(lo2, hi2, v1, s1); add(lo, hi, v2, s2); add(lo2, hi2, v3, s3);
         }
-        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4], scales[(int64_t)k * nby]);
+        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4], scale_of(k));
     }
     red[sl][cl] = lo + lo2;
     red[4 + sl][cl] = hi + hi2;
@@ -2729,7 +2746,8 @@ __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __rest
 __global__ __launch_bounds__(256) void slab_reduce_f16pair_kernel(const unsigned* __restrict__ slabs, float* __restrict__ out,
                                                                   int64_t npair, int row, int nsplit, int coblk) {
     __shared__ f32x4 red[8][64];
-    slab_reduce_block_f16pair(slabs, out, npair, row, nsplit, coblk, blockIdx.x, red);
+    __shared__ float sc_tab[512];
+    slab_reduce_block_f16pair(slabs, out, npair, row, nsplit, coblk, blockIdx.x, red, sc_tab);
 }
 
 // Every pending slab reduction of a backward pass in ONE launch (uh_slab_reduce_batched): the filter gradients only feed the
@@ -2738,6 +2756,7 @@ __global__ __launch_bounds__(256) void slab_reduce_f16pair_kernel(const unsigned
 constexpr int SLAB_TAB = 8;
 __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t* __restrict__ table, int nrows) {
     __shared__ f32x4 red[8][64];
+    __shared__ float sc_tab[512];
     const int64_t b = blockIdx.x;
     int r = 0;
     for (int k = 1; k < nrows; ++k)                   // (a few dozen rows at most; scalar loads)
@@ -2748,7 +2767,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t*
         slab_reduce_block_f32(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[2], (int)t[3], blk, red);
     else
         slab_reduce_block_f16pair(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]), t[2] / 2, (int)t[5],
-                                  (int)t[3], (int)t[7], blk, red);
+                                  (int)t[3], (int)t[7], blk, red, sc_tab);
 }
 
 // =====================================================================================
