@@ -697,10 +697,13 @@ __global__ __launch_bounds__(256 * KS, ((NBW == 1 && !WRES && !BSUM && KS == 1) 
     const int nslab = Cout / BN;
     const int nlanes = gridDim.x / nslab;
     int tile_lane, slab;
+#ifndef UH_XCD_BLOCK
+#define UH_XCD_BLOCK 0      // experiment (round 5): 1 = an XCD owns a CONTIGUOUS range of tile lanes (horizontally adjacent tiles share its L2), 0 = lanes dealt round-robin
+#endif
     if ((nlanes & 7) == 0) {
         const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
         slab = jj % nslab;
-        tile_lane = (jj / nslab) * 8 + xcd;
+        tile_lane = UH_XCD_BLOCK ? xcd * (nlanes >> 3) + jj / nslab : (jj / nslab) * 8 + xcd;
     } else {
         slab = blockIdx.x / nlanes;
         tile_lane = blockIdx.x - slab * nlanes;
