@@ -283,6 +283,42 @@ def test_g13_config5_convt_exact_fp32_with_cc_loss():
         close(t["grad_norm"], r[f"cfg5.s{s}.grad_norm"], 2e-3 if first else 3e-2, f"cfg5 grad_norm s{s}")
 
 
+def test_config5_at_its_per_gpu_size_against_the_reference_graph_on_the_cpu():
+    """BASELINE configs[4]'s per-GPU workload at size: UNet(1,1,bilinear=False) (64..1024, ConvTranspose Up blocks), exact fp32,
+    4 x 1x512x512 (batch 16 over 4 GPUs), with the connected_component_loss term on.  The reference's graph from stock torch.nn
+    modules (oracle/nn_ref.py) takes the same step on the host in fp32: logits at the north star's 1e-3, loss terms 1e-4 (the
+    boundary term 1e-3: thresholded counts), gradient norm 2e-3; the cc term (OpenCV-backed in the reference, parity unpinned) is
+    checked for what it may do: add a non-negative value to the loss and nothing else."""
+    import unet_amd
+    from oracle import nn_ref as N
+    dev = _dev()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g = torch.Generator().manual_seed(55)
+    im = torch.rand(4, 1, 512, 512, generator=g)
+    mk = torch.randint(0, 3, (4, 512, 512), generator=g)
+    torch.manual_seed(0)
+    model = unet_amd.UNet(1, 1, bilinear=False)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    twin = N.NNUNet(1, 1, False).to(memory_format=torch.channels_last)
+    twin.load_state_dict(state)
+    ref = N.NNStepper(twin).step(im.contiguous(memory_format=torch.channels_last), mk)
+    ref.pop("grads")
+    del twin
+    model = model.to(memory_format=torch.channels_last).to(dev)
+    st = unet_amd.TrainStepper(model, lr=1e-5, amp=False, cc_loss=True, fp32_mode="exact")
+    t = st.step(im.to(dev).contiguous(memory_format=torch.channels_last), mk.to(dev))
+    torch.cuda.synchronize()
+    check(t["logits"], ref["logits"], 1e-3, "cfg5@512 fp32 logits vs the CPU graph (max)")
+    for k in ("bce", "dice"):
+        close(t[k], ref[k], 1e-4, f"cfg5@512 fp32 {k}")
+    close(t["boundary"], ref["boundary"], 1e-3, "cfg5@512 fp32 boundary")
+    cc = float(t["cc"])
+    assert cc >= 0.0
+    close(float(t["loss"]) - cc, ref["loss"], 1e-4, "cfg5@512 fp32 loss without the cc term")
+    close(t["grad_norm"], ref["grad_norm"], 2e-3, "cfg5@512 fp32 grad_norm")
+    st.optimizer.close()
+
+
 def test_g13_config4_depth5_full_width():
     """BASELINE config 4's network at full width (64..2048/2, the 2048-channel two-source K loop in up1) on 1x3x64x64:
     CE + multiclass Dice + 0.2 * boundary (4-D path) against the reference-composed Depth5."""
