@@ -1,0 +1,36 @@
+#!/bin/bash
+# Store relaxation (UH_ST_RELAX on top of UH_W_EARLY): the waits of the first chunk behind an interior tile leave the NST output stores of
+# that tile in flight (vmcnt retires in order: a wait for a load issued behind them also waits for their acknowledgement).  Tests, then A/B.
+mkdir -p gpurun_out/r5s
+P=$PWD/scratch/libs
+UH_LIB_PATH=$P/libunet_hip_strel.so timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity.py tests/test_gpu_bnsum.py tests/test_gpu_bf16_vs_reference.py -q -m gpu -x > gpurun_out/r5s/tests.log 2>&1
+rc=$?; echo "variant tests rc=$rc"; tail -4 gpurun_out/r5s/tests.log
+[ $rc -eq 0 ] || exit 1
+for i in 1 2; do
+  python scratch/r4_conv_bench.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/r5s/base_$i.txt &&
+  UH_LIB_PATH=$P/libunet_hip_strel.so python scratch/r4_conv_bench.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/r5s/strel_$i.txt || exit 1
+done
+for i in 1 2 3; do
+  python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-inference --no-sustained --no-strong-leg 2>gpurun_out/r5s/bb_$i.err > gpurun_out/r5s/bb_$i.json &&
+  UH_LIB_PATH=$P/libunet_hip_strel.so python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-inference --no-sustained --no-strong-leg 2>gpurun_out/r5s/bw_$i.err > gpurun_out/r5s/bw_$i.json || exit 1
+done
+python - <<'PY'
+import re, json
+order = ["base_1", "strel_1", "base_2", "strel_2"]
+rows = {}
+for v in order:
+    for line in open("gpurun_out/r5s/%s.txt" % v):
+        m = re.match(r"(\S+)\s+H=\s*(\d+)\s+(\d+) ->\s*(\d+) \| fwd\s+([\d.]+) us .*\| dgrad\s+([\d.]+) us", line)
+        if m: rows.setdefault(m.group(1), {})[v] = (float(m.group(5)), float(m.group(6)))
+print("us per launch; columns:", order)
+for k, d in rows.items():
+    print(f"{k:8s} fwd  ", " ".join(f"{d[v][0]:7.1f}" if v in d else "      -" for v in order))
+    print(f"{k:8s} dgrad", " ".join(f"{d[v][1]:7.1f}" if v in d else "      -" for v in order))
+print("sum     ", " ".join(f"{sum(d[v][0] + d[v][1] for d in rows.values() if v in d):7.0f}" for v in order))
+for i in (1, 2, 3):
+    for t in ("bb", "bw"):
+        try:
+            j = json.loads(open(f"gpurun_out/r5s/{t}_{i}.json").read().strip().splitlines()[-1])
+            print(t, i, j["value"], "img/s", j["ms_per_step"], "ms | b4", j.get("b4", {}).get("value") if isinstance(j.get("b4"), dict) else None)
+        except Exception as e: print(t, i, "unreadable", e)
+PY
