@@ -2681,12 +2681,25 @@ __global__ __launch_bounds__(256) void slab_reduce_tall_kernel(const float* __re
 // rows / input channels); the inverse scales [nsplit][nby] (nby = (Cout / coblk) * (Cin / 64), block = cot * (Cin / 64) + cit) sit
 // behind the slabs.  npair = (Cout / 2) * row dwords per slab, row = 9 * Cin (a multiple of 4: a 16-byte piece stays inside one
 // row pair and one 64-channel block).
+//
+// Shape of a block: CL = 256 / SL columns (16-byte pieces) x SL split lanes.  The layers with FEW filter rows are the ones with MANY
+// splits (a 64 x 64-channel layer: 4 608 pieces x 512 splits; 512 x 512: 294 912 x 8), so a fixed 64 x 4 block left the shallow layers
+// with 72 workgroups whose threads each walked 128 slabs -- 41 us for 37 MB, against 9 us for the same bytes of a deep layer
+// (profiles/r05_slab_reduce_shapes.md).  SL follows the split count (uh_slab16_lanes: about eight slabs per thread, at least 128
+// contiguous bytes per split row of a wave); the sums stay in a fixed order: per thread as before, the SL lanes pairwise through LDS.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ inline int uh_slab16_lanes(int nsplit) { return nsplit >= 256 ? 32 : nsplit >= 128 ? 16 : nsplit >= 64 ? 8 : 4; }
+__host__ __device__ inline int64_t uh_slab16_blocks(int64_t npair, int nsplit) {
+    const int cl = 256 / uh_slab16_lanes(nsplit);
+    return ((npair >> 2) + cl - 1) / cl;
+}
+template <int SL>
 __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __restrict__ slabs, float* __restrict__ out,
                                                           int64_t npair, int row, int nsplit, int coblk, int64_t blk,
-                                                          f32x4 (*red)[64], float* sc_tab) {
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t i4 = blk * 64 + cl;
+                                                          f32x4* red, float* sc_tab) {
+    constexpr int CL = 256 / SL;
+    const int cl = threadIdx.x % CL, sl = threadIdx.x / CL;
+    const int64_t i4 = blk * CL + cl;
     const int64_t n4 = npair >> 2;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo, lo2 = lo, hi2 = lo;
     auto add = [](f32x4& l, f32x4& h, const u32x4 v, const float sc) {
@@ -2707,7 +2720,7 @@ __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __rest
     // The inverse scales of the workgroup's output-channel block -- [nsplit][nci] floats, at most 512 -- are staged in LDS once: read
     // one by one from memory they doubled the kernel's load instructions (15 us per launch against the bf16 form's 9.8).  A
     // workgroup's 256 dwords lie in one or two row pairs; a piece whose row pair belongs to the NEXT block takes the memory path.
-    const int64_t cp_first = ((blk * 64) << 2) / row;
+    const int64_t cp_first = ((blk * CL) << 2) / row;
     const int cot0 = (int)(2 * cp_first) / coblk;
     const bool staged = nsplit * nci <= 512;
     if (staged) {
@@ -2728,29 +2741,48 @@ __device__ __forceinline__ void slab_reduce_block_f16pair(const unsigned* __rest
         auto scale_of = [&](int k) -> float { return from_lds ? tab[k * nci] : scales[(int64_t)k * nby]; };
         const u32x4* base = reinterpret_cast<const u32x4*>(slabs) + i4;
         int k = sl;
-        for (; k + 12 < nsplit; k += 16) {           // four independent loads in flight per lane, added in a fixed order
-            const u32x4 v0 = base[(int64_t)k * n4], v1 = base[(int64_t)(k + 4) * n4];
-            const u32x4 v2 = base[(int64_t)(k + 8) * n4], v3 = base[(int64_t)(k + 12) * n4];
-            const float s0 = scale_of(k), s1 = scale_of(k + 4), s2 = scale_of(k + 8), s3 = scale_of(k + 12);
+        for (; k + 3 * SL < nsplit; k += 4 * SL) {   // four independent loads in flight per lane, added in a fixed order
+            const u32x4 v0 = base[(int64_t)k * n4], v1 = base[(int64_t)(k + SL) * n4];
+            const u32x4 v2 = base[(int64_t)(k + 2 * SL) * n4], v3 = base[(int64_t)(k + 3 * SL) * n4];
+            const float s0 = scale_of(k), s1 = scale_of(k + SL), s2 = scale_of(k + 2 * SL), s3 = scale_of(k + 3 * SL);
             add(lo, hi, v0, s0); add(lo2, hi2, v1, s1); add(lo, hi, v2, s2); add(lo2, hi2, v3, s3);
         }
-        for (; k < nsplit; k += 4) add(lo, hi, base[(int64_t)k * n4], scale_of(k));
+        for (; k < nsplit; k += SL) add(lo, hi, base[(int64_t)k * n4], scale_of(k));
     }
-    red[sl][cl] = lo + lo2;
-    red[4 + sl][cl] = hi + hi2;
+    // red[half][sl][cl]: the SL partial sums of a column meet pairwise (lane s += lane s + h, h = SL/2 ... 1: a fixed tree)
+    red[sl * CL + cl] = lo + lo2;
+    red[(SL + sl) * CL + cl] = hi + hi2;
     __syncthreads();
+#pragma unroll
+    for (int h = SL / 2; h >= 2; h >>= 1) {
+        if (sl < h) {
+            red[sl * CL + cl] += red[(sl + h) * CL + cl];
+            red[(SL + sl) * CL + cl] += red[(SL + sl + h) * CL + cl];
+        }
+        __syncthreads();
+    }
     if (sl < 2 && i4 < n4) {                          // split lane 0 writes the even rows, lane 1 the odd ones
-        const int o = 4 * sl;
-        const f32x4 v = (red[o][cl] + red[o + 1][cl]) + (red[o + 2][cl] + red[o + 3][cl]);
+        const f32x4 v = red[(sl * SL) * CL + cl] + red[(sl * SL + 1) * CL + cl];
         *reinterpret_cast<f32x4*>(out + (2 * cp + sl) * row + rem) = v;
+    }
+}
+template <typename F>
+__device__ __forceinline__ void slab16_dispatch(int nsplit, F&& f) {
+    switch (uh_slab16_lanes(nsplit)) {          // (block-uniform)
+        case 32: f(std::integral_constant<int, 32>{}); break;
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 8: f(std::integral_constant<int, 8>{}); break;
+        default: f(std::integral_constant<int, 4>{}); break;
     }
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_f16pair_kernel(const unsigned* __restrict__ slabs, float* __restrict__ out,
                                                                   int64_t npair, int row, int nsplit, int coblk) {
-    __shared__ f32x4 red[8][64];
+    __shared__ f32x4 red[512];
     __shared__ float sc_tab[512];
-    slab_reduce_block_f16pair(slabs, out, npair, row, nsplit, coblk, blockIdx.x, red, sc_tab);
+    slab16_dispatch(nsplit, [&](auto sl) {
+        slab_reduce_block_f16pair<decltype(sl)::value>(slabs, out, npair, row, nsplit, coblk, blockIdx.x, red, sc_tab);
+    });
 }
 
 // Every pending slab reduction of a backward pass in ONE launch (uh_slab_reduce_batched): the filter gradients only feed the
@@ -2758,7 +2790,7 @@ __global__ __launch_bounds__(256) void slab_reduce_f16pair_kernel(const unsigned
 // the gradients are needed.  table[r] = { slabs, out, n, nsplit, format (0 fp32, 1 scaled fp16 pairs), row, first block, coblk } (int64).
 constexpr int SLAB_TAB = 8;
 __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t* __restrict__ table, int nrows) {
-    __shared__ f32x4 red[8][64];
+    __shared__ f32x4 red[512];
     __shared__ float sc_tab[512];
     const int64_t b = blockIdx.x;
     int r = 0;
@@ -2767,10 +2799,13 @@ __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const int64_t*
     const int64_t* t = table + r * SLAB_TAB;
     const int64_t blk = b - t[6];
     if (t[4] == 0)
-        slab_reduce_block_f32(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[2], (int)t[3], blk, red);
+        slab_reduce_block_f32(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[2], (int)t[3], blk,
+                              reinterpret_cast<f32x4(*)[64]>(red));
     else
-        slab_reduce_block_f16pair(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]), t[2] / 2, (int)t[5],
-                                  (int)t[3], (int)t[7], blk, red, sc_tab);
+        slab16_dispatch((int)t[3], [&](auto sl) {
+            slab_reduce_block_f16pair<decltype(sl)::value>(reinterpret_cast<const unsigned*>(t[0]), reinterpret_cast<float*>(t[1]),
+                                                           t[2] / 2, (int)t[5], (int)t[3], (int)t[7], blk, red, sc_tab);
+        });
 }
 
 // =====================================================================================
@@ -3713,12 +3748,12 @@ static int conv3x3_wgrad_dispatch(const T* dy, int lddy, const T* x0, int C0, in
     if (defer && n % 4 == 0 && uh_aligned16(dw) && uh_aligned16(slabs)) {
         defer[0] = (int64_t)(uintptr_t)slabs; defer[1] = (int64_t)(uintptr_t)dw; defer[2] = n; defer[3] = p.nsplit;
         defer[4] = slab16 ? 1 : 0; defer[5] = 9 * Cin; defer[7] = 32 * p.nwr;
-        defer[6] = slab16 ? (n / 2 / 4 + 63) / 64 : (n / 4 + 63) / 64;      // blocks of the reduction (the caller turns it into an offset)
+        defer[6] = slab16 ? uh_slab16_blocks(n / 2, p.nsplit) : (n / 4 + 63) / 64;      // blocks of the reduction (the caller turns it into an offset)
         return UH_OK;
     }
     if (slab16) {
         const int64_t npair = n / 2;
-        hipLaunchKernelGGL(slab_reduce_f16pair_kernel, dim3((unsigned)((npair / 4 + 63) / 64)), dim3(256), 0, st,
+        hipLaunchKernelGGL(slab_reduce_f16pair_kernel, dim3((unsigned)uh_slab16_blocks(npair, p.nsplit)), dim3(256), 0, st,
                            (const unsigned*)slabs, dw, npair, 9 * Cin, p.nsplit, 32 * p.nwr);
         UH_CHECK_LAUNCH("slab_reduce_f16pair_kernel");
         return UH_OK;
