@@ -782,10 +782,12 @@ def _wgrad_errors(x, dy, dev):
     return e_ours, e_ref, float((ours - dwref).abs().max() / dwref.abs().max())
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 128, 128, 128, 256), (2, 256, 256, 64, 64), (4, 32, 32, 512, 512)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 128, 128, 128, 256), (2, 256, 256, 64, 64), (4, 32, 32, 512, 512), (2, 128, 128, 128, 128),
+                                            (2, 120, 136, 64, 128)])
 def test_16_bit_slabs_are_more_precise_than_the_reference_rounding_of_the_total(B, H, W, Cin, Cout):
     """The per-split partial sums of bf16 backward-weights travel to the reduce kernel as block-scaled fp16 pairs (SLAB16) and are
-    added in fp32.  The reference's autocast backward returns the filter gradient in bf16, i.e. it rounds the TOTAL.  On
+    added in fp32 (the shapes take the reduce kernel through its 8, 32, 4, 16 and 32 split-lane blocks: 64, 512, 8, 128, 256 splits;
+    the last one with border tiles).  The reference's autocast backward returns the filter gradient in bf16, i.e. it rounds the TOTAL.  On
     i.i.d. gradients the partials, added in quadrature, are about as large as the total, and fp16 carries three more bits than
     bf16: the error against fp64 stays far below that single rounding of the total."""
     dev = _dev()
