@@ -1,12 +1,14 @@
 #!/bin/bash
 # Which unit the forward conv kernel waits for, shipped library against the no-filter-loads diagnostic build (scratch/libs/libunet_hip_abl_NOW.so):
-# two --pmc passes each over scratch/r5_pmc_probe.py.      scratch/r5_pmc_ablate.sh <outdir under gpurun_out>
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$1; mkdir -p $OUT
+# two --pmc passes each over scratch/r5_pmc_probe.py.      scratch/r5_pmc_ablate.sh <outdir under gpurun_out> [variant ...]
+# (variants = suffixes of scratch/libs/libunet_hip_<variant>.so; default "abl_NOW"; "base" = the shipped library, always first)
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$1; mkdir -p $OUT; shift
+VARS="base ${@:-abl_NOW}"
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_ANY"
 P2="TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum"
-for v in base NOW; do
-  if [ $v = base ]; then unset UH_LIB_PATH; else export UH_LIB_PATH=$R/scratch/libs/libunet_hip_abl_$v.so; fi
+for v in $VARS; do
+  if [ $v = base ]; then unset UH_LIB_PATH; else export UH_LIB_PATH=$R/scratch/libs/libunet_hip_$v.so; fi
   for p in 1 2; do
     if [ $p = 1 ]; then P=$P1; else P=$P2; fi
     rocprofv3 --kernel-trace --pmc $P -d $OUT/${v}_p$p -- python3 $R/scratch/r5_pmc_probe.py > $OUT/${v}_p$p.log 2>&1 || { echo "$v pass $p failed"; tail -5 $OUT/${v}_p$p.log; exit 1; }
@@ -15,8 +17,8 @@ for v in base NOW; do
   done
 done
 unset UH_LIB_PATH
-python3 - <<PY
-import csv, collections
+VARS="$VARS" python3 - <<PY
+import csv, collections, os
 names = ["up1.0 1024->512 @64", "down2.3 256->256 @128", "up4.0 128->64 @512", "inc.3 64->64 @512"]
 def load(d):
     rows = collections.OrderedDict()
@@ -27,11 +29,11 @@ def load(d):
         e["dur"] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
     return list(rows.values())
 out = ["# rocprofv3 --pmc passes over scratch/r5_pmc_probe.py (4 forward conv shapes of config 2, batch 8, bf16; last 3 of 4 launches averaged):",
-       "# base = the shipped library, NOW = the diagnostic build without filter-fragment loads in the chunk loop (scratch/libs/libunet_hip_abl_NOW.so, results garbage by design).",
+       "# base = the shipped library; the others = scratch/libs/libunet_hip_<lib>.so (abl_NOW: no filter-fragment loads in the chunk loop, results garbage by design; wearly / strel: scratch/r5/conv_w_early_store_relax.diff).",
        "# mfma_ghz_equiv = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / duration (utilisation x clock); wait_inst = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; vmem_rd = SQ_INSTS_VMEM_RD per launch;",
        "# ta_busy = TA_BUSY_avr / (GRBM-free estimate: duration x 2.0 GHz) is NOT normalised here: the raw average busy cycles per TA are listed; tcc_hit = TCC_HIT / (HIT + MISS).",
        "layer,lib,dur_us,mfma_ghz_equiv,wait_inst_frac,wait_any_frac,vmem_rd_insts,ta_busy_avr_cycles,tcp_tcc_read_req,tcp_pending_stall_cycles,tcc_hit_rate"]
-for v in ("base", "NOW"):
+for v in os.environ["VARS"].split():
     a, b = load("$OUT/%s_c1" % v), load("$OUT/%s_c2" % v)
     for i, n in enumerate(names):
         ga, gb = a[4 * i + 1:4 * i + 4], b[4 * i + 1:4 * i + 4]
