@@ -199,3 +199,30 @@ def test_upsample_to_2gib_samples_and_adjoint():
     sq += float((t * t).sum())
     # u and dx are rounded to bf16 (2^-9 relative, independent per element): the two sums differ by a random walk
     assert abs(lhs - rhs) < 6.0 * 2.0 ** -8 * sq ** 0.5, (lhs, rhs, sq ** 0.5)
+
+
+def test_transposed_conv_backward_takes_a_strided_gradient_past_2gib():
+    """Up's ConvTranspose2d (unet_parts.py:73) receives its gradient as the [.., C:] half of the concatenated tensor's gradient
+    (unet_parts.py:95).  At 32 x 512 x 512 x 64 bf16 channels that half is 1 GiB packed but a 2 GiB walk at the concatenated
+    tensor's pixel stride -- past the MFMA kernels' buffer window (bench.py --convt stopped there in its global-batch-32 leg).  The
+    op packs such a gradient first: the result must be bit-identical to the packed call."""
+    from unet_amd import ops
+    dev = _dev()
+    Bn, hh, Cin, Cout = 32, 256, 128, 64
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(Bn, hh, hh, Cin, device=dev, dtype=torch.bfloat16, generator=g).requires_grad_(True)
+    wt = (torch.randn(Cin, Cout, 2, 2, device=dev, generator=g) * 0.05).requires_grad_(True)
+    b = torch.zeros(Cout, device=dev).requires_grad_(True)
+    cat = torch.randn(Bn, 2 * hh, 2 * hh, 2 * Cout, device=dev, dtype=torch.bfloat16, generator=g)     # 2 GiB: the concatenated gradient
+    dy_strided = cat[..., Cout:]
+    assert ops.pixel_ld(dy_strided) == 2 * Cout and cat.numel() * cat.element_size() == 1 << 31
+    y = ops.ConvTranspose2x2PadFn.apply(x, wt, b, 2 * hh, 2 * hh)
+    got = torch.autograd.grad(y, [x, wt, b], dy_strided, retain_graph=True)
+    want = torch.autograd.grad(y, [x, wt, b], dy_strided.contiguous())
+    for a, c in zip(got, want):
+        assert torch.equal(a, c)
+    # and the values are those of the transposed conv: one batch element against torch on the CPU
+    xs = x.detach()[:1, :32, :32].float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    ws = wt.detach().bfloat16().float().cpu().requires_grad_(True)
+    ys = F.conv_transpose2d(xs, ws, None, stride=2)
+    assert float((y.detach()[:1, :64, :64].float().cpu().permute(0, 3, 1, 2) - ys).abs().max()) < 2e-2 * float(ys.abs().max())

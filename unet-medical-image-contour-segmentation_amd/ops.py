@@ -1394,6 +1394,11 @@ class ConvTranspose2x2PadFn(Function):
         dy = dense_nhwc(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dt = ctx.dt
         mfma = wd is not None
+        # dy usually is the [.., C:] half of the gradient of the concatenated tensor (pixel stride 2 x Cout): the MFMA kernels address
+        # it through a 2 GiB buffer window that uh_convt2x2_mfma_ok sized for the PACKED tensor -- pack it when the strided walk
+        # would pass that window (32 x 512 x 512 x 64 bf16 channels inside a 128-channel gradient: bench.py's global-batch-32 leg)
+        if mfma and dy.shape[0] * dy.shape[1] * dy.shape[2] * pixel_ld(dy) * dy.element_size() >= (1 << 31) - 4096:
+            dy = dy.contiguous()
         flops = 2.0 * B * h * w * Cin * 4 * Cout
         dx = None
         if ctx.needs_input_grad[0]:
