@@ -420,7 +420,7 @@ def main():
     strong_gb32 = None
     # (N = 1 runs it too -- 32 images on the one GPU -- so that the 1 -> N scaling of the fixed global batch, the north star's
     # ">= 6x at batch 32 x 512 x 512", is the ratio of two `strong_gb32.images_per_sec` figures measured the same way)
-    if not strong and not args.config4 and 32 % world == 0 and not args.no_strong_leg and not args.graph and B == 8 and (world > 1 or S == 512):
+    if not strong and not args.config4 and 32 % world == 0 and not args.no_strong_leg and not args.graph and B == 8 and (world > 1 or S <= 512):
         b2 = 32 // world
         im2, mk2 = make_batch(b2, 101 + rank)
         try:
